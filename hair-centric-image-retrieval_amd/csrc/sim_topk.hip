@@ -1,0 +1,719 @@
+// sim_topk.hip — brute-force query x gallery cosine / inner-product top-k.
+//
+// Replaces sklearn KNeighborsClassifier(metric="cosine").kneighbors
+// (HP/src/classification_engine.py:80-82), cosine_similarity + argsort
+// (src/models/hair_encoder.py:193-194) and torch.mm + torch.sort
+// (HP/src/neg_sampling.py:37,45-51).  See include/hcir.h for the contract.
+//
+// Structure (DESIGN.md "sim_topk"):
+//   scan   : every workgroup streams gallery tiles (sim_core.h) against one block
+//            of <=128 queries; each lane owns one query column and keeps a sorted
+//            top-KP list in registers; lists of a workgroup are merged through LDS
+//            and written as one partial list per (workgroup, query).
+//   merge  : one wave per query merges the partial lists (k rounds of wave arg-max
+//            over per-lane cached list heads).
+//   prefix : for big galleries the first S rows are scanned and merged first; the
+//            k-th score of that prefix is a per-query floor for the main scan, so
+//            that register-list insertions become rare there (a gallery row with
+//            score <= floor can never enter the final top-k: every prefix row has
+//            a smaller index and wins the tie).
+//   k > 64 : repeated passes, each taking the next <=64 ranks below a per-query
+//            ceiling (val, idx) left by the previous pass.
+#include "sim_core.h"
+
+namespace {
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// Sorted (score desc, arrival order) register list.  Callers feed increasing row
+// indices, so equal scores keep the smaller index first.  Precondition: s > v[KP-1].
+template <int KP>
+__device__ __forceinline__ void topk_insert(float (&v)[KP], int (&id)[KP], float s, int i) {
+#pragma unroll
+  for (int j = KP - 1; j > 0; --j) {
+    const bool up = s > v[j - 1];
+    const bool here = s > v[j];
+    v[j] = up ? v[j - 1] : (here ? s : v[j]);
+    id[j] = up ? id[j - 1] : (here ? i : id[j]);
+  }
+  const bool top = s > v[0];
+  v[0] = top ? s : v[0];
+  id[0] = top ? i : id[0];
+}
+template <int KP>
+__device__ __forceinline__ float topk_kth(const float (&v)[KP], int k) {
+  // select chain kept opaque: hipcc otherwise rewrites it as v[k-1] through scratch
+  float t = v[KP - 1];
+#pragma unroll
+  for (int j = 0; j < KP - 1; ++j) {
+    t = (j == k - 1) ? v[j] : t;
+    asm volatile("" : "+v"(t));
+  }
+  return t;
+}
+
+struct ScanArgs {
+  const void* q;
+  const void* g;
+  const float* qn;         // [nq] or null
+  const float* gn;         // [ng] or null
+  const float* floor_val;  // [nq] or null: only scores > floor are candidates
+  const float* ceil_val;   // [nq] or null: only (score, idx) strictly after
+  const int* ceil_idx;     //   (ceil_val, ceil_idx) in (desc, asc) order are candidates
+  float* part_val;         // [nparts][nq][KP]
+  int* part_idx;
+  int64_t nq, row_begin, row_end;  // gallery rows [row_begin, row_end)
+  int d, k;
+};
+
+template <typename T, int KP, int QT, int WQ, int WGG>
+__global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
+  using Cfg = SimCfg<T, WGG, WQ, QT>;
+  constexpr int EPS = SimElem<T>::kPerStage;
+  constexpr int NSRC = 2 * WGG;  // lists per query inside a workgroup
+  // queries merged per LDS round (power of two, the lists must fit the staging LDS)
+  constexpr int QR_FIT = Cfg::LDS_BYTES / (NSRC * KP * 8);
+  constexpr int QR = QR_FIT >= Cfg::QB ? Cfg::QB : (QR_FIT >= 64 ? 64 : (QR_FIT >= 32 ? 32 : 16));
+  static_assert(QR * NSRC * KP * 8 <= Cfg::LDS_BYTES, "merge round must fit LDS");
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_g = wave / WQ, wave_q = wave % WQ;
+  const int r = lane & 31, h = lane >> 5;
+  const T* __restrict__ g = static_cast<const T*>(a.g);
+  const T* __restrict__ q = static_cast<const T*>(a.q);
+  const int64_t q_row0 = (int64_t)blockIdx.y * Cfg::QB;
+  const int64_t q_last = a.nq - 1;
+
+  // per-lane query state
+  float lv[QT][KP];
+  int li[QT][KP];
+  float thr[QT], qnv[QT], cval[QT];
+  int cidx[QT];
+  int64_t myq[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      lv[qt][j] = kNegInf;
+      li[qt][j] = -1;
+    }
+    myq[qt] = q_row0 + wave_q * (32 * QT) + qt * 32 + r;
+    const bool live = myq[qt] < a.nq;
+    const int64_t qc = live ? myq[qt] : q_last;
+    qnv[qt] = a.qn ? a.qn[qc] : 1.0f;
+    thr[qt] = a.floor_val ? a.floor_val[qc] : kNegInf;
+    cval[qt] = a.ceil_val ? a.ceil_val[qc] : __builtin_huge_valf();
+    cidx[qt] = a.ceil_val ? a.ceil_idx[qc] : -1;
+  }
+  float floorv[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) floorv[qt] = thr[qt];
+
+  const int nkc = (a.d + EPS - 1) / EPS;
+  const int64_t nrows = a.row_end - a.row_begin;
+  const int64_t ntiles = (nrows + Cfg::GM - 1) / Cfg::GM;
+  const int64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t nsteps = my_tiles * nkc;
+  const int64_t g_last = a.row_end - 1;
+
+  f32x16 acc[2][QT];
+#pragma unroll
+  for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[gt][qt][i] = 0.f;
+
+  u32x4 regs[Cfg::NLOAD];
+  if (nsteps > 0) {
+    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * Cfg::GM;
+    sim_stage_load<T, Cfg>(regs, g, row0, g_last, q, q_row0, q_last, a.d, 0, tid);
+    sim_stage_store<Cfg>(regs, lds, tid);
+  }
+  __syncthreads();
+
+  int64_t tile_i = 0;  // index among my tiles
+  int kc = 0;
+  for (int64_t step = 0; step < nsteps; ++step) {
+    const int cur = (int)(step & 1);
+    // prefetch next stage (possibly first chunk of my next tile)
+    int nkc_next = kc + 1;
+    int64_t ntile_i = tile_i;
+    if (nkc_next == nkc) {
+      nkc_next = 0;
+      ntile_i = tile_i + 1;
+    }
+    const bool has_next = step + 1 < nsteps;
+    if (has_next) {
+      const int64_t row0n = a.row_begin + ((int64_t)blockIdx.x + ntile_i * gridDim.x) * Cfg::GM;
+      sim_stage_load<T, Cfg>(regs, g, row0n, g_last, q, q_row0, q_last, a.d, nkc_next, tid);
+    }
+    sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
+    if (has_next) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+
+    if (kc == nkc - 1) {
+      // ---- per-tile epilogue: scale the 16 scores of each 32x32 tile, mask the ones
+      //      above the lane's threshold, then pop candidates in row order into the list
+      const int64_t row0 = a.row_begin + ((int64_t)blockIdx.x + tile_i * gridDim.x) * Cfg::GM;
+#pragma unroll
+      for (int gt = 0; gt < 2; ++gt) {
+        const int64_t rbase = row0 + wave_g * 64 + gt * 32 + 4 * h;
+        float gnv[16];
+        if (a.gn) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int64_t row = rbase + (i & 3) + 8 * (i >> 2);
+            gnv[i] = a.gn[row < a.row_end ? row : g_last];
+          }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          unsigned mask = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int64_t row = rbase + (i & 3) + 8 * (i >> 2);
+            float s = acc[gt][qt][i];
+            if (a.gn) s = s * gnv[i];
+            if (a.qn) s = s * qnv[qt];
+            acc[gt][qt][i] = s;
+            bool cand = (row < a.row_end) && (s > thr[qt]);
+            if (a.ceil_val)
+              cand = cand && ((s < cval[qt]) || (s == cval[qt] && (int)row > cidx[qt]));
+            mask |= cand ? (1u << i) : 0u;
+          }
+          // wave-uniform slot loop: acc[..][i] with a scalar i stays in registers
+          // (movrel), a per-lane index would be lowered through scratch.
+          unsigned any = mask;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
+          any = __builtin_amdgcn_readfirstlane(any);
+          while (any != 0u) {
+            const int i = __builtin_ctz(any);
+            any &= any - 1u;
+            const float s = acc[gt][qt][i];
+            if (((mask >> i) & 1u) && s > thr[qt]) {
+              topk_insert<KP>(lv[qt], li[qt], s, (int)(rbase + (i & 3) + 8 * (i >> 2)));
+              thr[qt] = fmaxf(floorv[qt], topk_kth<KP>(lv[qt], a.k));
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[gt][qt][i] = 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    kc = nkc_next;
+    tile_i = ntile_i;
+  }
+
+  // ---- merge the NSRC lists of each query through LDS, one thread per query,
+  //      QR queries per round
+  float* mv = reinterpret_cast<float*>(lds);
+  int* mi = reinterpret_cast<int*>(lds + QR * NSRC * KP * 4);
+  for (int q0r = 0; q0r < Cfg::QB; q0r += QR) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int ql = wave_q * (32 * QT) + qt * 32 + r - q0r;
+      const int src = wave_g * 2 + h;
+      if (ql >= 0 && ql < QR) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+          mv[(ql * NSRC + src) * KP + j] = lv[qt][j];
+          mi[(ql * NSRC + src) * KP + j] = li[qt][j];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < QR && q_row0 + q0r + tid < a.nq) {
+      const float* lv = mv + tid * NSRC * KP;
+      const int* li = mi + tid * NSRC * KP;
+      unsigned long long heads = 0;  // 8 bits per source
+      float* ov = a.part_val + ((int64_t)blockIdx.x * a.nq + q_row0 + q0r + tid) * KP;
+      int* oi = a.part_idx + ((int64_t)blockIdx.x * a.nq + q_row0 + q0r + tid) * KP;
+      for (int o = 0; o < KP; ++o) {
+        float bv = kNegInf;
+        int bi = -1, bs = -1;
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s) {
+          const int hd = (int)((heads >> (8 * s)) & 0xff);
+          if (hd < KP) {
+            const float v = lv[s * KP + hd];
+            const int id = li[s * KP + hd];
+            if (id >= 0 && (bs < 0 || v > bv || (v == bv && id < bi))) {
+              bv = v;
+              bi = id;
+              bs = s;
+            }
+          }
+        }
+        ov[o] = bv;
+        oi[o] = bi;
+        if (bs >= 0) heads += 1ull << (8 * bs);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------------------
+// merge: one wave per query; lists [nlists][nq][kin] sorted (desc, idx asc),
+// empty slots have idx < 0.  Lane l owns lists l, l+64, ... (<= LPL of them) and
+// caches each list's head; k_out rounds of wave arg-max.
+// --------------------------------------------------------------------------
+constexpr int kMergeLPL = 9;  // lists per lane -> 576 lists per pass
+
+template <typename IdxT>
+struct MergeArgs {
+  const float* vals;
+  const IdxT* idx;
+  float* out_val;
+  int64_t* out_idx;      // final output (idx_base added), or
+  int* out_idx32;        // intermediate output
+  float* kth_val;        // optional [nq]: value of rank k_out-1 (floor for the main scan)
+  int* kth_idx;          // optional [nq]
+  int64_t nq, idx_base;
+  int nlists, kin, kout;
+  // optional extra list per query (the prefix result), [nq][kin_extra]
+  const float* extra_val;
+  const int* extra_idx;
+  int kin_extra;
+};
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= a.nq) return;
+  const bool has_extra = a.extra_val != nullptr;
+  const int total = a.nlists + (has_extra ? 1 : 0);
+
+  float cv[kMergeLPL];
+  int64_t ci[kMergeLPL];
+  int hd[kMergeLPL];
+  auto fetch = [&](int list, int pos, float& v, int64_t& id) {
+    v = kNegInf;
+    id = -1;
+    if (list < a.nlists) {
+      if (pos < a.kin) {
+        const int64_t o = ((int64_t)list * a.nq + qi) * a.kin + pos;
+        v = a.vals[o];
+        id = (int64_t)a.idx[o];
+      }
+    } else if (list < total) {
+      if (pos < a.kin_extra) {
+        v = a.extra_val[qi * a.kin_extra + pos];
+        id = a.extra_idx[qi * a.kin_extra + pos];
+      }
+    }
+    if (id < 0) v = kNegInf;
+  };
+#pragma unroll
+  for (int j = 0; j < kMergeLPL; ++j) {
+    hd[j] = 0;
+    fetch(lane + 64 * j, 0, cv[j], ci[j]);
+  }
+  for (int o = 0; o < a.kout; ++o) {
+    float bv = cv[0];
+    int64_t bi = ci[0];
+    int bj = 0;
+#pragma unroll
+    for (int j = 1; j < kMergeLPL; ++j) {
+      const bool take = (ci[j] >= 0) && (bi < 0 || better(cv[j], ci[j], bv, bi));
+      bv = take ? cv[j] : bv;
+      bi = take ? ci[j] : bi;
+      bj = take ? j : bj;
+    }
+    // wave arg-max under (score desc, idx asc); empty = idx < 0
+    float wv = bv;
+    int64_t wi = bi;
+    int wl = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(wv, off);
+      const int64_t oi = __shfl_xor(wi, off);
+      const int ol = __shfl_xor(wl, off);
+      const bool take = (oi >= 0) && (wi < 0 || better(ov, oi, wv, wi));
+      wv = take ? ov : wv;
+      wi = take ? oi : wi;
+      wl = take ? ol : wl;
+    }
+    if (lane == 0) {
+      a.out_val[qi * a.kout + o] = wv;
+      if (a.out_idx) a.out_idx[qi * a.kout + o] = wi < 0 ? -1 : wi + a.idx_base;
+      if (a.out_idx32) a.out_idx32[qi * a.kout + o] = (int)wi;
+      if (o == a.kout - 1) {
+        if (a.kth_val) a.kth_val[qi] = wi < 0 ? kNegInf : wv;
+        if (a.kth_idx) a.kth_idx[qi] = (int)wi;
+      }
+    }
+    if (lane == wl && wi >= 0) {
+#pragma unroll
+      for (int j = 0; j < kMergeLPL; ++j) {
+        if (j == bj) {
+          hd[j] += 1;
+          fetch(lane + 64 * j, hd[j], cv[j], ci[j]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ x, int64_t n, int d,
+                                                          int64_t ldx, float eps,
+                                                          float* __restrict__ out) {
+  // one wave per row; lane l sums elements 4*(l + 64 j) + e in order, then an
+  // xor butterfly 32,16,...,1 (mirrored by oracle/knn_oracle.c: hcir_oracle_row_invnorm).
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const T* p = x + row * ldx;
+  float s = 0.f;
+  for (int k = 4 * lane; k < d; k += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = (float)p[k + e];
+      s = __builtin_fmaf(v, v, s);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[row] = 1.0f / fmaxf(sqrtf(s), eps);
+}
+
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int64_t n,
+                                                           int d, float eps, float* __restrict__ y32,
+                                                           _Float16* __restrict__ y16) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* p = x + row * (int64_t)d;
+  float s = 0.f;
+  for (int k = 4 * lane; k < d; k += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = __builtin_fmaf(p[k + e], p[k + e], s);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float nrm = fmaxf(sqrtf(s), eps);
+  for (int k = 4 * lane; k < d; k += 256) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = p[k + e] / nrm;
+      if (y32) y32[row * (int64_t)d + k + e] = v;
+      if (y16) y16[row * (int64_t)d + k + e] = (_Float16)v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void convert_kernel(const float* __restrict__ x, int64_t n, T* __restrict__ y) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[i + e] = (T)v[e];
+  }
+  if (i < n && i + 3 >= n)
+    for (int64_t j = i; j < n; ++j) y[j] = (T)x[j];
+}
+
+__global__ void pass_copy_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int64_t nq,
+                                 int kk, int k, int done, int64_t idx_base,
+                                 float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq * kk) return;
+  const int64_t qi = t / kk;
+  const int j = (int)(t % kk);
+  out_val[qi * k + done + j] = pv[t];
+  out_idx[qi * k + done + j] = pi[t] < 0 ? -1 : (int64_t)pi[t] + idx_base;
+}
+
+// ----- host-side planning ---------------------------------------------------
+struct Plan {
+  int kp;          // list capacity per pass (16 or 64)
+  int qb;          // queries per workgroup (32, 64, 128)
+  int gm;          // gallery rows per workgroup tile
+  int64_t prefix;  // rows of the prefix scan (== ng: single scan)
+  int grid_main;   // workgroups (x) of the widest scan
+  int npass;       // passes for k > 64
+};
+
+constexpr int kMaxGridX = 512;  // 2 workgroups per CU; also <= 576 lists per merge pass
+
+Plan make_plan(int64_t nq, int64_t ng, int k) {
+  Plan p;
+  p.kp = k <= 16 ? 16 : 64;
+  p.npass = (k + 63) / 64;
+  if (p.kp == 64) {
+    p.qb = 32;
+  } else {
+    p.qb = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+  }
+  p.gm = p.qb == 128 ? 128 : 256;
+  const int64_t tiles = hcir_cdiv(ng, p.gm);
+  p.grid_main = (int)(tiles < kMaxGridX ? tiles : kMaxGridX);
+  // prefix: ~1/16 of the gallery, at least 64 rows per list-k, in whole tiles
+  p.prefix = ng;
+  if (p.npass == 1 && ng >= 32768) {
+    int64_t s = ng / 16;
+    const int64_t lo = 8192, hi = 131072;
+    s = s < lo ? lo : (s > hi ? hi : s);
+    s = hcir_cdiv(s, p.gm) * p.gm;
+    if (s < ng) p.prefix = s;
+  }
+  return p;
+}
+
+struct Workspace {
+  float* part_val;
+  int* part_idx;
+  float* pre_val;  // [nq][kp] prefix / previous-pass result
+  int* pre_idx;
+  float* floor_val;  // [nq]
+  float* ceil_val;   // [nq]
+  int* ceil_idx;     // [nq]
+  size_t bytes;
+};
+
+Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
+  Workspace w;
+  char* c = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    char* r = c ? c + off : nullptr;
+    off += (n + 255) & ~size_t(255);
+    return r;
+  };
+  const size_t part = (size_t)kMaxGridX * nq * p.kp;
+  w.part_val = reinterpret_cast<float*>(take(part * 4));
+  w.part_idx = reinterpret_cast<int*>(take(part * 4));
+  w.pre_val = reinterpret_cast<float*>(take((size_t)nq * p.kp * 4));
+  w.pre_idx = reinterpret_cast<int*>(take((size_t)nq * p.kp * 4));
+  w.floor_val = reinterpret_cast<float*>(take((size_t)nq * 4));
+  w.ceil_val = reinterpret_cast<float*>(take((size_t)nq * 4));
+  w.ceil_idx = reinterpret_cast<int*>(take((size_t)nq * 4));
+  (void)k;
+  w.bytes = off;
+  return w;
+}
+
+template <typename T, int KP, int QT, int WQ, int WGG>
+void launch_scan_cfg(const ScanArgs& a, int grid_x, int grid_y, hipStream_t st) {
+  hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+}
+
+template <typename T>
+void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
+  const int grid_y = (int)hcir_cdiv(a.nq, p.qb);
+  if (p.kp == 64) {
+    launch_scan_cfg<T, 64, 1, 1, 4>(a, grid_x, grid_y, st);
+  } else if (p.qb == 32) {
+    launch_scan_cfg<T, 16, 1, 1, 4>(a, grid_x, grid_y, st);
+  } else if (p.qb == 64) {
+    launch_scan_cfg<T, 16, 2, 1, 4>(a, grid_x, grid_y, st);
+  } else {
+    launch_scan_cfg<T, 16, 2, 2, 2>(a, grid_x, grid_y, st);
+  }
+}
+
+void launch_scan_dtype(int dtype, const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
+  if (dtype == HCIR_F32)
+    launch_scan<float>(p, a, grid_x, st);
+  else if (dtype == HCIR_F16)
+    launch_scan<_Float16>(p, a, grid_x, st);
+  else
+    launch_scan<__bf16>(p, a, grid_x, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hcir_sim_topk_workspace_bytes(int64_t nq, int64_t ng, int32_t d, int32_t k, int dtype) {
+  (void)d;
+  (void)dtype;
+  if (nq <= 0 || ng <= 0 || k <= 0) return 0;
+  const Plan p = make_plan(nq, ng, k);
+  return carve(nullptr, nq, k, p).bytes;
+}
+
+int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t d, int32_t k,
+                  int dtype, const float* q_inv_norm, const float* g_inv_norm, int64_t idx_base,
+                  float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  if (!q || !g || !out_val || !out_idx) return HCIR_ERR_INVALID;
+  if (nq <= 0 || ng <= 0 || d <= 0 || (d & 7) || k <= 0 || k > HCIR_TOPK_MAX) return HCIR_ERR_INVALID;
+  if (k > ng || ng >= (int64_t(1) << 31)) return HCIR_ERR_INVALID;
+  if (dtype != HCIR_F32 && dtype != HCIR_F16 && dtype != HCIR_BF16) return HCIR_ERR_UNSUPPORTED;
+  const Plan p = make_plan(nq, ng, k);
+  Workspace w = carve(workspace, nq, k, p);
+  if (!workspace || workspace_bytes < w.bytes) return HCIR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int merge_grid = (int)hcir_cdiv(nq, 4);
+
+  ScanArgs a{};
+  a.q = q;
+  a.g = g;
+  a.qn = q_inv_norm;
+  a.gn = g_inv_norm;
+  a.part_val = w.part_val;
+  a.part_idx = w.part_idx;
+  a.nq = nq;
+  a.d = d;
+
+  if (p.npass == 1) {
+    a.k = k;
+    const bool two_phase = p.prefix < ng;
+    // phase A: rows [0, prefix)
+    a.row_begin = 0;
+    a.row_end = p.prefix;
+    const int64_t tiles_a = hcir_cdiv(p.prefix, p.gm);
+    const int grid_a = (int)(tiles_a < kMaxGridX ? tiles_a : kMaxGridX);
+    launch_scan_dtype(dtype, p, a, grid_a, st);
+    HCIR_LAUNCH_CHECK();
+    MergeArgs<int> m{};
+    m.vals = w.part_val;
+    m.idx = w.part_idx;
+    m.nq = nq;
+    m.nlists = grid_a;
+    m.kin = p.kp;
+    m.kout = k;
+    if (!two_phase) {
+      m.out_val = out_val;
+      m.out_idx = out_idx;
+      m.idx_base = idx_base;
+      hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+      HCIR_LAUNCH_CHECK();
+      return HCIR_OK;
+    }
+    m.out_val = w.pre_val;
+    m.out_idx32 = w.pre_idx;
+    m.kth_val = w.floor_val;
+    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+    HCIR_LAUNCH_CHECK();
+    // phase B: rows [prefix, ng) with the prefix k-th score as floor
+    a.row_begin = p.prefix;
+    a.row_end = ng;
+    a.floor_val = w.floor_val;
+    const int64_t tiles_b = hcir_cdiv(ng - p.prefix, p.gm);
+    const int grid_b = (int)(tiles_b < kMaxGridX ? tiles_b : kMaxGridX);
+    launch_scan_dtype(dtype, p, a, grid_b, st);
+    HCIR_LAUNCH_CHECK();
+    MergeArgs<int> m2{};
+    m2.vals = w.part_val;
+    m2.idx = w.part_idx;
+    m2.nq = nq;
+    m2.nlists = grid_b;
+    m2.kin = p.kp;
+    m2.kout = k;
+    m2.extra_val = w.pre_val;
+    m2.extra_idx = w.pre_idx;
+    m2.kin_extra = k;
+    m2.out_val = out_val;
+    m2.out_idx = out_idx;
+    m2.idx_base = idx_base;
+    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m2);
+    HCIR_LAUNCH_CHECK();
+    return HCIR_OK;
+  }
+
+  // k > 64: successive passes of <= 64 ranks below a moving ceiling.
+  a.row_begin = 0;
+  a.row_end = ng;
+  const int grid_x = p.grid_main;
+  int done = 0;
+  for (int pass = 0; pass < p.npass; ++pass) {
+    const int kk = (k - done) < 64 ? (k - done) : 64;
+    a.k = kk;
+    a.ceil_val = pass ? w.ceil_val : nullptr;
+    a.ceil_idx = pass ? w.ceil_idx : nullptr;
+    launch_scan_dtype(dtype, p, a, grid_x, st);
+    HCIR_LAUNCH_CHECK();
+    MergeArgs<int> m{};
+    m.vals = w.part_val;
+    m.idx = w.part_idx;
+    m.nq = nq;
+    m.nlists = grid_x;
+    m.kin = p.kp;
+    m.kout = kk;
+    m.out_val = w.pre_val;
+    m.out_idx32 = w.pre_idx;
+    m.kth_val = w.ceil_val;
+    m.kth_idx = w.ceil_idx;
+    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+    HCIR_LAUNCH_CHECK();
+    // scatter this pass's [nq][kk] block into out[:, done:done+kk]
+    hipLaunchKernelGGL(pass_copy_kernel, dim3((unsigned)hcir_cdiv(nq * kk, 256)), dim3(256), 0, st,
+                       w.pre_val, w.pre_idx, nq, kk, k, done, idx_base, out_val, out_idx);
+    HCIR_LAUNCH_CHECK();
+    done += kk;
+  }
+  return HCIR_OK;
+}
+
+int hcir_topk_merge(const float* vals, const int64_t* idx, int32_t nlists, int64_t nq, int32_t k_in,
+                    int32_t k_out, float* out_val, int64_t* out_idx, void* stream) {
+  if (!vals || !idx || !out_val || !out_idx) return HCIR_ERR_INVALID;
+  if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return HCIR_ERR_INVALID;
+  if (nlists > 64 * kMergeLPL) return HCIR_ERR_UNSUPPORTED;
+  MergeArgs<int64_t> m{};
+  m.vals = vals;
+  m.idx = idx;
+  m.nq = nq;
+  m.nlists = nlists;
+  m.kin = k_in;
+  m.kout = k_out;
+  m.out_val = out_val;
+  m.out_idx = out_idx;
+  m.idx_base = 0;
+  hipLaunchKernelGGL(topk_merge_kernel<int64_t>, dim3((int)hcir_cdiv(nq, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), m);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_row_invnorm(const void* x, int64_t n, int32_t d, int64_t ldx, int dtype, float eps,
+                     float* out, void* stream) {
+  if (!x || !out || n <= 0 || d <= 0 || (d & 3) || ldx < d) return HCIR_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)hcir_cdiv(n, 4)), block(256);
+  if (dtype == HCIR_F32)
+    hipLaunchKernelGGL(row_invnorm_kernel<float>, grid, block, 0, st, (const float*)x, n, d, ldx, eps, out);
+  else if (dtype == HCIR_F16)
+    hipLaunchKernelGGL(row_invnorm_kernel<_Float16>, grid, block, 0, st, (const _Float16*)x, n, d, ldx, eps, out);
+  else if (dtype == HCIR_BF16)
+    hipLaunchKernelGGL(row_invnorm_kernel<__bf16>, grid, block, 0, st, (const __bf16*)x, n, d, ldx, eps, out);
+  else
+    return HCIR_ERR_UNSUPPORTED;
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_l2_normalize(const float* x, int64_t n, int32_t d, float eps, float* y_f32, void* y_f16,
+                      void* stream) {
+  if (!x || n <= 0 || d <= 0 || (d & 3)) return HCIR_ERR_INVALID;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, n, d, eps, y_f32, (_Float16*)y_f16);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream) {
+  if (!x || !y || n <= 0) return HCIR_ERR_INVALID;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t blocks = hcir_cdiv(n, 1024);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == HCIR_F16)
+    hipLaunchKernelGGL(convert_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (_Float16*)y);
+  else if (dtype == HCIR_BF16)
+    hipLaunchKernelGGL(convert_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (__bf16*)y);
+  else
+    return HCIR_ERR_UNSUPPORTED;
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+"""ctypes loader for libhcir.so (the C ABI declared in include/hcir.h).
+
+The product path has no CPU fallback: if the library is missing, or an op is handed
+a tensor that is not on a HIP device, it raises.  `build()` compiles the library
+in-tree with hipcc (make -C csrc); it does not need a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libhcir.so")
+
+F32, F16, BF16 = 0, 1, 2
+EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_AFFINE_RELU_F16, EPI_AFFINE_F32 = range(6)
+
+_lib = None
+
+c_i32, c_i64, c_f32, c_vp, c_sz, c_int = (
+    ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+
+# name -> (restype, argtypes); must list every symbol of include/hcir.h
+SIGNATURES = {
+    "hcir_version": (c_int, []),
+    "hcir_status_string": (ctypes.c_char_p, [c_int]),
+    "hcir_row_invnorm": (c_int, [c_vp, c_i64, c_i32, c_i64, c_int, c_f32, c_vp, c_vp]),
+    "hcir_l2_normalize": (c_int, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "hcir_sim_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32, c_int]),
+    "hcir_sim_topk": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_int, c_vp, c_vp, c_i64,
+                              c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_topk_merge": (c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "hcir_ntxent_workspace_bytes": (c_sz, [c_i64, c_i32, c_int]),
+    "hcir_ntxent_fwd": (c_int, [c_vp, c_vp, c_i64, c_i32, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_layernorm_f16": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "hcir_gemm_f16": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,
+                              c_vp, c_i64, c_vp]),
+    "hcir_patch_embed": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                 c_f32, c_i32, c_vp, c_vp]),
+    "hcir_attn_fwd": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "hcir_cls_head": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_int, c_vp, c_vp, c_vp]),
+    "hcir_patch_mean": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+}
+
+
+class HcirError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libhcir.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load libhcir.so; raises HcirError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HcirError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C csrc). "
+                "There is no CPU fallback for the hcir hot path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().hcir_status_string(status).decode()
+        raise HcirError(f"{what} failed: {msg} (status {status})")

@@ -1,0 +1,186 @@
+/*
+ * hcir.h — C ABI of libhcir.so, the MI355X (gfx950) retrieval hot path.
+ *
+ * The reference (atunnd/Hair-centric-Image-Retrieval) has no FFI: its hot path is
+ * Python calling torch / torchvision / lightly / scikit-learn.  Each entry point
+ * below replaces one of those library calls; the reference call site it stands in
+ * for is cited as  <file>:<line>  relative to the reference root
+ * (HP/ = HairPretraining/).  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add at each site.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch tensor
+ *     .data_ptr()); the library allocates nothing and keeps no global state.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *     .cuda_stream); every call is asynchronous on that stream.
+ *   - Return value: HCIR_OK (0) or a negative hcir_status.  Nothing throws
+ *     across the ABI.  hcir_status_string() maps a code to text.
+ *   - Row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ *   - Tie-break of every top-k: score descending, then index ascending.
+ */
+#ifndef HCIR_H
+#define HCIR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  HCIR_OK = 0,
+  HCIR_ERR_INVALID = -1,      /* bad argument (null pointer, k > n, d % 8 != 0 ...) */
+  HCIR_ERR_UNSUPPORTED = -2,  /* valid request this build has no kernel for       */
+  HCIR_ERR_LAUNCH = -3,       /* HIP reported a launch error                      */
+  HCIR_ERR_WORKSPACE = -4     /* workspace too small                              */
+} hcir_status;
+
+typedef enum {
+  HCIR_F32 = 0, /* fp32 storage, exact-fp32 MFMA (k-ordered fmaf chain)    */
+  HCIR_F16 = 1, /* fp16 storage, fp16 MFMA, fp32 accumulate               */
+  HCIR_BF16 = 2 /* bf16 storage, bf16 MFMA, fp32 accumulate               */
+} hcir_dtype;
+
+int hcir_version(void);
+const char* hcir_status_string(int status);
+
+/* ------------------------------------------------------------------ *
+ * Row norms.  out[i] = 1 / max(||x_i||_2, eps)   (fp32)
+ * Replaces the normalisation half of
+ *   sklearn cosine_similarity / cosine_distances   (HP/src/classification_engine.py:80-82,
+ *                                                    src/models/hair_encoder.py:193)
+ *   embeddings / norm.clamp(min=1e-8)               (HP/src/neg_sampling.py:35)
+ * ------------------------------------------------------------------ */
+int hcir_row_invnorm(const void* x, int64_t n, int32_t d, int64_t ldx, int dtype,
+                     float eps, float* out, void* stream);
+
+/* In-place-capable L2 normalise of fp32 rows, optional second output in fp16:
+ *   y = x / max(||x||, eps)            torch.nn.functional.normalize(x, dim=1)
+ * (HP/src/classification_engine.py:50,62).  y_f32 and/or y_f16 may be NULL. */
+int hcir_l2_normalize(const float* x, int64_t n, int32_t d, float eps, float* y_f32,
+                      void* y_f16, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * Brute-force cosine / inner-product top-k:  query x gallery.
+ *   score[i][j] = <q_i, g_j> * (q_inv_norm ? q_inv_norm[i] : 1)
+ *                            * (g_inv_norm ? g_inv_norm[j] : 1)
+ *   out_val[i][0..k) = the k largest scores of row i, descending
+ *   out_idx[i][0..k) = idx_base + j of those scores (ties: smaller j first)
+ * Replaces
+ *   KNeighborsClassifier(metric="cosine").kneighbors   HP/src/classification_engine.py:80-82
+ *   cosine_similarity + np.argsort[::-1][:top_k]       src/models/hair_encoder.py:193-194
+ *   torch.mm + torch.sort (rank-k pick)                HP/src/neg_sampling.py:37,45-51
+ * The Q x N score matrix is never materialised.  dtype is the storage type of
+ * BOTH q and g.  HCIR_F32 scores are bit-reproducible: each score is one fp32
+ * fmaf chain over k in the order documented in DESIGN.md ("sim_topk k-order"),
+ * which oracle/knn_oracle.c follows.
+ * Requirements: d % 8 == 0, 1 <= k <= min(ng, HCIR_TOPK_MAX), ng < 2^31.
+ * ------------------------------------------------------------------ */
+#define HCIR_TOPK_MAX 1024
+size_t hcir_sim_topk_workspace_bytes(int64_t nq, int64_t ng, int32_t d, int32_t k,
+                                     int dtype);
+int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t d,
+                  int32_t k, int dtype, const float* q_inv_norm,
+                  const float* g_inv_norm, int64_t idx_base, float* out_val,
+                  int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* Merge `nlists` sorted top-k lists per query into one top-k_out list.
+ * vals/idx layout: [nlists][nq][k_in].  Used for the per-shard merge after the
+ * RCCL all-gather (no reference equivalent: the reference is single-GPU,
+ * SURVEY.md §2.3) and internally by hcir_sim_topk.  Entries with idx < 0 are
+ * empty slots. */
+int hcir_topk_merge(const float* vals, const int64_t* idx, int32_t nlists, int64_t nq,
+                    int32_t k_in, int32_t k_out, float* out_val, int64_t* out_idx,
+                    void* stream);
+
+/* ------------------------------------------------------------------ *
+ * NT-Xent forward (lightly.loss.NTXentLoss semantics; call site
+ * HP/src/pretrain_engine.py:93,725; in-tree restatement
+ * experiments/DualViewHair/src/losses/ntxent_loss.py:30-57).
+ *   z = [normalize(z0); normalize(z1)]  (2B x D),  logits = z z^T * inv_t,
+ *   diagonal removed, positive of row i is (i + B) mod 2B,
+ *   loss = mean_i ( logsumexp_{j != i} logits[i][j] - logits[i][pos(i)] ).
+ * Outputs: loss (1 float), row_lse[2B] (saved for a backward pass, may be NULL).
+ * The 2B x 2B logits are never materialised.  d % 8 == 0.
+ * ------------------------------------------------------------------ */
+size_t hcir_ntxent_workspace_bytes(int64_t b, int32_t d, int dtype);
+int hcir_ntxent_fwd(const void* z0, const void* z1, int64_t b, int32_t d, int dtype,
+                    float inv_t, float* loss, float* row_lse, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * ViT building blocks (fp16 MFMA, fp32 accumulate, fp32 residual stream).
+ * ------------------------------------------------------------------ */
+
+/* LayerNorm over the last dim of fp32 rows -> fp16 rows.
+ * nn.LayerNorm(D, eps=1e-6)   torchvision EncoderBlock.ln_1/ln_2 (HP/src/main_backbone.py:554)
+ *                             models_vit.LayerNorm (HP/src/models_vit.py:23-27) */
+int hcir_layernorm_f16(const float* x, int64_t rows, int32_t d, int64_t ldx,
+                       const float* gamma, const float* beta, float eps, void* y_f16,
+                       int64_t ldy, void* stream);
+
+/* Epilogues of hcir_gemm_f16:  acc = A[M,K] . W[N,K]^T  (fp32 accumulate) */
+typedef enum {
+  HCIR_EPI_BIAS_F16 = 0,      /* out_f16 = acc + bias                      (qkv / in_proj)      */
+  HCIR_EPI_BIAS_GELU_F16 = 1, /* out_f16 = gelu_erf(acc + bias)            (mlp fc1)            */
+  HCIR_EPI_BIAS_RESID_F32 = 2,/* out_f32 += scale[n] * (acc + bias)        (attn proj, mlp fc2; */
+                              /*   scale = LayerScale gamma or NULL)                            */
+  HCIR_EPI_BIAS_F32 = 3,      /* out_f32 = acc + bias                                           */
+  HCIR_EPI_AFFINE_RELU_F16 = 4,/* out_f16 = relu(acc * scale[n] + bias[n])  (proj-head Linear+BN+ReLU, eval) */
+  HCIR_EPI_AFFINE_F32 = 5     /* out_f32 = acc * scale[n] + bias[n]        (proj-head Linear+BN, eval)      */
+} hcir_epilogue;
+
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T).  A, W fp16 row-major (W is the
+ * nn.Linear weight as stored).  Replaces nn.Linear / MultiheadAttention
+ * in_proj / out_proj / MLPBlock / timm Mlp  (HP/src/models_vit.py:63,66,70,79;
+ * HP/src/main_backbone.py:554 -> torchvision EncoderBlock).
+ * Requirements: K % 8 == 0, N % 8 == 0; bias may be NULL. */
+int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
+                  const float* bias, const float* scale, int64_t m, int32_t n,
+                  int32_t k, int epilogue, void* out, int64_t ldo, void* stream);
+
+/* Patch embedding = Conv2d(C, D, kernel=P, stride=P) as an im2col-free MFMA GEMM
+ * over the fp32 NCHW image, fused with bias, class token and positional add:
+ *   tok[b][0]     = cls + pos_mult * pos[0]
+ *   tok[b][1 + p] = W . patch(b,p) + bias + pos_mult * pos[1 + p]
+ * (HP/src/main_backbone.py:543-551 with pos_mult = 2, see DESIGN.md "double
+ *  positional add"; HP/src/models_vit.py:42,48,229-233 with pos_mult = 1).
+ * img fp32 [B][C][H][W]; w fp16 [D][C*P*P]; tok fp32 [B][1 + (H/P)(W/P)][D]. */
+int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px,
+                     int32_t p, const void* w_f16, const float* bias, const float* cls,
+                     const float* pos, float pos_mult, int32_t d, float* tok,
+                     void* stream);
+
+/* Fused multi-head self-attention forward over packed qkv:
+ *   qkv fp16 [B][T][3][H][hd]  (rows of the in_proj / qkv GEMM),
+ *   out fp16 [B][T][H*hd] = softmax((q * scale) k^T) v   per (b, head).
+ * K and V of one (b, head) are LDS-resident; QK^T and PV are MFMA 32x32x16
+ * tiles; softmax stays in registers.  (HP/src/models_vit.py:69-78;
+ * nn.MultiheadAttention inside torchvision EncoderBlock, HP/src/main_backbone.py:554.)
+ * Requirements: hd == 64, T <= 288. */
+int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
+                  float scale, void* out, void* stream);
+
+/* Final step of extract_features for the CLS token:
+ *   e = ln ? LayerNorm(tok[b][0]) : tok[b][0];  optionally L2-normalised.
+ * (torchvision Encoder.ln + x[:,0]  HP/src/main_backbone.py:554,557;
+ *  F.normalize  HP/src/classification_engine.py:50.)
+ * emb_f32 [B][D]; emb_f16 optional. */
+int hcir_cls_head(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
+                  const float* beta, float eps, int l2_normalize, float* emb_f32,
+                  void* emb_f16, void* stream);
+
+/* Mean over patch tokens 1..T-1 after the optional final LayerNorm
+ * (pooled_patches of ViTWrapper.forward, HP/src/main_backbone.py:558-561). */
+int hcir_patch_mean(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
+                    const float* beta, float eps, float* out_f32, void* stream);
+
+/* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
+int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCIR_H */

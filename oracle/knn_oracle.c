@@ -1,0 +1,195 @@
+/*
+ * knn_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the reference's brute-force cosine kNN, used only
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+ * checker for libhcir.so.  Nothing under hair-centric-image-retrieval_amd/ may
+ * link, import or call it.
+ *
+ * What it restates
+ *   - sklearn KNeighborsClassifier(metric="cosine").kneighbors as used by
+ *     Classifier.knn_eval            HP/src/classification_engine.py:79-82
+ *       S = normalize(X) normalize(Y)^T ; d = 1 - S ; k smallest d, sorted
+ *   - cosine_similarity + argsort[::-1][:k]   src/models/hair_encoder.py:193-194
+ *   - normalise + mm + sort, pick rank k      HP/src/neg_sampling.py:35-51
+ * scikit-learn (un-pinned in requirements.txt:1-8; 1.7.2 installed here) holds the
+ * arithmetic; tests/test_oracle_knn.py pins this file against sklearn itself and
+ * against tests/golden/knn_*.npz generated from sklearn by tests/golden/make_golden.py.
+ *
+ * Tie-break: score descending, then index ascending.  The reference is not
+ * consistent on exact ties (argpartition order in sklearn; highest index first in
+ * hair_encoder.py because of argsort()[::-1]); SURVEY.md §7 fixes this choice.
+ *
+ * fp32 "chain" mode reproduces libhcir's HCIR_F32 scores bit for bit: one fmaf
+ * chain per score over k in the order of sim_core.h ("sim_topk k-order"):
+ *   for each 32-element chunk c: for cc in 0..3: for e in 0..3:
+ *       k = 32c + 8cc + e,  then  k + 4
+ * (elements past d contribute fmaf(0,0,acc)).  "f64" mode accumulates in double in
+ * natural order and is the precision reference for fp16/bf16 storage.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_MODE_CHAIN32 0
+#define ORACLE_MODE_F64 1
+
+int hcir_oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* 1 / max(||x||, eps) with libhcir's summation order (row_invnorm_kernel):
+ * lane l of 64 sums elements 4(l + 64 j) + e by fmaf, then an xor butterfly. */
+void hcir_oracle_row_invnorm(const float* x, int64_t n, int32_t d, int64_t ldx, float eps,
+                             float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t row = 0; row < n; ++row) {
+    const float* p = x + row * ldx;
+    float part[64];
+    for (int l = 0; l < 64; ++l) {
+      float s = 0.f;
+      for (int k = 4 * l; k < d; k += 256)
+        for (int e = 0; e < 4; ++e) s = fmaf(p[k + e], p[k + e], s);
+      part[l] = s;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      float nxt[64];
+      for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ off];
+      memcpy(part, nxt, sizeof(part));
+    }
+    out[row] = 1.0f / fmaxf(sqrtf(part[0]), eps);
+  }
+}
+
+static inline float dot_chain32(const float* g, const float* q, int d) {
+  float acc = 0.f;
+  const int nchunk = (d + 31) / 32;
+  for (int c = 0; c < nchunk; ++c) {
+    for (int cc = 0; cc < 4; ++cc) {
+      for (int e = 0; e < 4; ++e) {
+        const int k0 = 32 * c + 8 * cc + e, k1 = k0 + 4;
+        const float a0 = k0 < d ? g[k0] : 0.f, b0 = k0 < d ? q[k0] : 0.f;
+        const float a1 = k1 < d ? g[k1] : 0.f, b1 = k1 < d ? q[k1] : 0.f;
+        acc = fmaf(a0, b0, acc);
+        acc = fmaf(a1, b1, acc);
+      }
+    }
+  }
+  return acc;
+}
+
+static inline float dot_f64(const float* g, const float* q, int d) {
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) acc += (double)g[k] * (double)q[k];
+  return (float)acc;
+}
+
+static inline int better(float sa, int64_t ia, float sb, int64_t ib) {
+  return (sa > sb) || (sa == sb && ia < ib);
+}
+
+/* Full scores of one query (for tolerance-aware comparisons in tests). */
+void hcir_oracle_scores(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
+                        const float* qn, const float* gn, int mode, float* out /*[nq][ng]*/) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < nq; ++i) {
+    for (int64_t j = 0; j < ng; ++j) {
+      float s = mode == ORACLE_MODE_CHAIN32 ? dot_chain32(g + j * d, q + i * d, d)
+                                            : dot_f64(g + j * d, q + i * d, d);
+      if (gn) s = s * gn[j];
+      if (qn) s = s * qn[i];
+      out[i * ng + j] = s;
+    }
+  }
+}
+
+/* score = (<g_j, q_i> * gn[j]) * qn[i]; top-k per query, (desc, idx asc). */
+void hcir_oracle_cosine_topk(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
+                             int32_t k, const float* qn, const float* gn, int64_t idx_base,
+                             int mode, float* out_val, int64_t* out_idx) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t i = 0; i < nq; ++i) {
+    float* v = out_val + i * k;
+    int64_t* id = out_idx + i * k;
+    int filled = 0;
+    for (int64_t j = 0; j < ng; ++j) {
+      float s = mode == ORACLE_MODE_CHAIN32 ? dot_chain32(g + j * d, q + i * d, d)
+                                            : dot_f64(g + j * d, q + i * d, d);
+      if (gn) s = s * gn[j];
+      if (qn) s = s * qn[i];
+      if (s != s) continue; /* NaN never ranks */
+      if (filled == k && !better(s, j, v[k - 1], id[k - 1])) continue;
+      int p = filled < k ? filled : k - 1;
+      while (p > 0 && better(s, j, v[p - 1], id[p - 1])) {
+        v[p] = v[p - 1];
+        id[p] = id[p - 1];
+        --p;
+      }
+      v[p] = s;
+      id[p] = j;
+      if (filled < k) ++filled;
+    }
+    for (int p = filled; p < k; ++p) {
+      v[p] = -INFINITY;
+      id[p] = -1;
+    }
+    for (int p = 0; p < filled; ++p) id[p] += idx_base;
+  }
+}
+
+/* Merge nlists sorted lists [nlists][nq][kin] into [nq][kout]. */
+void hcir_oracle_topk_merge(const float* vals, const int64_t* idx, int32_t nlists, int64_t nq,
+                            int32_t kin, int32_t kout, float* out_val, int64_t* out_idx) {
+  for (int64_t i = 0; i < nq; ++i) {
+    int* head = (int*)calloc((size_t)nlists, sizeof(int));
+    for (int o = 0; o < kout; ++o) {
+      int bl = -1;
+      float bv = 0.f;
+      int64_t bi = 0;
+      for (int l = 0; l < nlists; ++l) {
+        if (head[l] >= kin) continue;
+        const int64_t off = ((int64_t)l * nq + i) * kin + head[l];
+        if (idx[off] < 0) continue;
+        if (bl < 0 || better(vals[off], idx[off], bv, bi)) {
+          bl = l;
+          bv = vals[off];
+          bi = idx[off];
+        }
+      }
+      if (bl < 0) {
+        out_val[i * kout + o] = -INFINITY;
+        out_idx[i * kout + o] = -1;
+      } else {
+        out_val[i * kout + o] = bv;
+        out_idx[i * kout + o] = bi;
+        head[bl]++;
+      }
+    }
+    free(head);
+  }
+}
+
+/* Uniform-weight kNN vote, smallest label wins ties (sklearn
+ * KNeighborsClassifier.predict with weights="uniform"; scipy.stats.mode).
+ * HP/src/classification_engine.py:82. */
+void hcir_oracle_knn_vote(const int64_t* nbr_idx, int64_t nq, int32_t k, const int64_t* labels,
+                          int64_t nclass, int64_t* pred) {
+  int64_t* cnt = (int64_t*)malloc((size_t)nclass * sizeof(int64_t));
+  for (int64_t i = 0; i < nq; ++i) {
+    memset(cnt, 0, (size_t)nclass * sizeof(int64_t));
+    for (int j = 0; j < k; ++j) cnt[labels[nbr_idx[i * k + j]]]++;
+    int64_t best = 0;
+    for (int64_t c = 1; c < nclass; ++c)
+      if (cnt[c] > cnt[best]) best = c;
+    pred[i] = best;
+  }
+  free(cnt);
+}

@@ -1,0 +1,143 @@
+"""GPU parity: hcir_sim_topk / hcir_topk_merge / hcir_row_invnorm vs oracle/knn_oracle.c.
+
+HCIR_F32 is compared BIT-EXACTLY (values and indices): libhcir's score is one fp32
+fmaf chain in a documented k-order which the C oracle follows.  fp16/bf16 storage is
+compared against the float64 oracle within a stated tolerance, indices exact wherever
+the oracle's score gaps exceed that tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn as oknn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(hcir_built):
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from hcir import ops as _ops
+    return _ops
+
+
+def _rand(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+CASES_F32 = [
+    # nq, ng, d, k
+    (1, 37, 8, 5),          # single query, tiny ragged gallery, minimum d
+    (5, 1000, 64, 10),
+    (64, 1000, 2048, 5),    # BASELINE config C1 shape
+    (64, 10000, 768, 10),   # BASELINE config C2 shape
+    (33, 777, 72, 16),      # ragged everything, d not a multiple of the 32-chunk
+    (128, 4099, 768, 10),
+    (200, 3000, 128, 7),    # two query blocks
+    (16, 50000, 768, 10),   # two-phase (prefix + floor) path
+    (70, 40000, 256, 3),
+]
+
+
+@pytest.mark.parametrize("nq,ng,d,k", CASES_F32)
+def test_sim_topk_f32_bit_exact(ops, nq, ng, d, k):
+    q, g = _rand((nq, d), 1), _rand((ng, d), 2)
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), k)
+    rv, ri = oknn.cosine_topk(q, g, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)
+
+
+def test_row_invnorm_bit_exact(ops):
+    for n, d in ((7, 8), (1000, 768), (33, 2048), (5, 1000)):
+        x = _rand((n, d), 3) * 3.0
+        out = ops.row_invnorm(torch.from_numpy(x).cuda(), 1e-12)
+        np.testing.assert_array_equal(out.cpu().numpy(), oknn.row_invnorm(x, 1e-12))
+
+
+def test_sim_topk_f32_norms_bit_exact(ops):
+    """cosine of un-normalised rows: (<g,q> * gn) * qn, the hair_encoder.py:193 path."""
+    q, g = _rand((9, 768), 4) * 2.5, _rand((5000, 768), 5) * 0.3
+    qd, gd = torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda()
+    qn, gn = ops.row_invnorm(qd, 1e-12), ops.row_invnorm(gd, 1e-12)
+    val, idx = ops.sim_topk(qd, gd, 5, q_inv_norm=qn, g_inv_norm=gn, idx_base=1000)
+    rv, ri = oknn.cosine_topk(q, g, 5, qn=oknn.row_invnorm(q, 1e-12), gn=oknn.row_invnorm(g, 1e-12),
+                              idx_base=1000)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)
+
+
+def test_sim_topk_planted_ties(ops):
+    """Exact ties resolve to the smaller index (documented tie-break)."""
+    g = _rand((3000, 64), 6)
+    g[17] = g[5]
+    g[2999] = g[5]
+    g[1234] = g[5]
+    q = np.stack([g[5] * 2.0, g[100]]).astype(np.float32)
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), 6)
+    rv, ri = oknn.cosine_topk(q, g, 6)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    assert list(idx[0, :4].cpu().numpy()) == [5, 17, 1234, 2999]
+
+
+@pytest.mark.parametrize("k", [17, 64, 100, 642])
+def test_sim_topk_large_k(ops, k):
+    """k up to 642 is in the reference's sweep (HP/src/classification_engine.py:71)."""
+    q, g = _rand((20, 128), 7), _rand((3000, 128), 8)
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), k)
+    rv, ri = oknn.cosine_topk(q, g, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)
+
+
+def test_sim_topk_k_equals_ng_and_errors(ops):
+    q, g = _rand((3, 16), 9), _rand((12, 16), 10)
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), 12)
+    rv, ri = oknn.cosine_topk(q, g, 12)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    with pytest.raises(ValueError):  # sklearn raises when n_neighbors > n_samples_fit
+        ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), 13)
+    from hcir import HcirError
+    with pytest.raises(HcirError):  # no CPU fallback
+        ops.sim_topk(torch.from_numpy(q), torch.from_numpy(g), 3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("nq,ng,d,k", [(64, 10000, 768, 10), (128, 60000, 768, 10), (3, 500, 64, 5)])
+def test_sim_topk_reduced_precision(ops, dtype, tol, nq, ng, d, k):
+    """fp16/bf16 storage: compare against float64 scores of the SAME rounded inputs.
+    Tolerance `tol` is absolute on unit-norm cosine scores (fp32 accumulate of exact
+    products: the only error is fp32 summation, so it is far tighter than input rounding)."""
+    q, g = _rand((nq, d), 11), _rand((ng, d), 12)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    qd, gd = torch.from_numpy(q).cuda().to(dtype), torch.from_numpy(g).cuda().to(dtype)
+    val, idx = ops.sim_topk(qd, gd, k)
+    qr, gr = qd.float().cpu().numpy(), gd.float().cpu().numpy()   # rounded inputs, exact in fp32
+    s = qr.astype(np.float64) @ gr.astype(np.float64).T
+    rv, ri = oknn.stable_topk_np(s, k + 1)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy()
+    np.testing.assert_allclose(val, rv[:, :k], atol=1e-5, rtol=0)
+    gap = rv[:, :-1] - rv[:, 1:]            # gaps between consecutive oracle ranks
+    safe = np.minimum(np.concatenate([np.full((nq, 1), np.inf), gap[:, :-1]], 1), gap) > 1e-5
+    np.testing.assert_array_equal(idx[safe], ri[:, :k][safe])
+    # and against the unrounded fp32 inputs within the storage tolerance
+    s32 = q.astype(np.float64) @ g.astype(np.float64).T
+    rv32, _ = oknn.stable_topk_np(s32, k)
+    np.testing.assert_allclose(val, rv32, atol=tol, rtol=0)
+
+
+def test_topk_merge(ops):
+    rng = np.random.default_rng(13)
+    nl, nq, kin, kout = 8, 50, 10, 10
+    vals = np.sort(rng.standard_normal((nl, nq, kin)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    idx = np.empty((nl, nq, kin), dtype=np.int64)
+    for l in range(nl):
+        idx[l] = l * 1000 + np.sort(rng.integers(0, 1000, (nq, kin)), axis=1)
+    vals[3, :, 7:] = -np.inf   # ragged shard: empty slots
+    idx[3, :, 7:] = -1
+    vals[1, 0, 0] = vals[2, 0, 0] = 5.0  # cross-shard tie -> smaller index
+    ov, oi = ops.topk_merge(torch.from_numpy(vals).cuda(), torch.from_numpy(idx).cuda(), kout)
+    rv, ri = oknn.topk_merge(vals, idx, kout)
+    np.testing.assert_array_equal(oi.cpu().numpy(), ri)
+    np.testing.assert_array_equal(ov.cpu().numpy(), rv)

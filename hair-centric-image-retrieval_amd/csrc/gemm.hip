@@ -1,0 +1,310 @@
+// gemm.hip — out[M,N] = epilogue(A[M,K] . W[N,K]^T), fp16 MFMA, fp32 accumulate.
+//
+// Replaces nn.Linear / nn.MultiheadAttention in_proj,out_proj / MLPBlock / timm Mlp
+// on the ViT path (HP/src/models_vit.py:63,66,70,79; torchvision EncoderBlock via
+// HP/src/main_backbone.py:554) and Conv2d(3,768,16,16) patch embedding
+// (HP/src/main_backbone.py:543; HP/src/models_vit.py:42,48).
+//
+// Tile engine: sim_core.h with W rows on the MFMA row index and activation rows on
+// the MFMA column index: a lane owns ONE activation row m and receives the output
+// features n in groups of 4 consecutive registers, so the epilogue reads/writes
+// 8 B (fp16) or 16 B (fp32) per lane per group.  Workgroup tile 128(n) x 128(m) x 64(k),
+// 4 waves as 2(n) x 2(m), each wave 2x2 MFMA 32x32x16 tiles, LDS double buffer,
+// global loads register-staged one k-chunk ahead.
+#include "sim_core.h"
+
+namespace {
+
+using GemmCfg = SimCfg<_Float16, 2, 2, 2>;  // GM = 128 W rows, QB = 128 A rows
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+struct GemmArgs {
+  const _Float16* a;
+  const _Float16* w;
+  const float* bias;
+  const float* scale;
+  void* out;
+  int64_t m, lda, ldw, ldo;
+  int n, k;
+};
+
+// XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8
+// XCDs (MI355X_MICROARCH.md §Workgroup dispatch); remap so that one XCD walks a
+// contiguous run of tiles and re-uses the W panel / A panel from its own L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2],
+                                              int64_t m0, int n0, int wave_n, int wave_m, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int64_t m = m0 + wave_m * 64 + mt * 32 + r;
+    if (m >= g.m) continue;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const int n = n0 + wave_n * 64 + nt * 32 + 8 * grp + 4 * h;
+        if (n >= g.n) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * grp + e];
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+        if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32) {
+          const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], s[e], b[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if constexpr (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 ||
+                      EPI == HCIR_EPI_AFFINE_RELU_F16) {
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
+            if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) x = fmaxf(x, 0.f);
+            o[e] = (_Float16)x;
+          }
+          *reinterpret_cast<f16x4*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+        } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+          float* p = static_cast<float*>(g.out) + m * g.ldo + n;
+          f32x4 o = *reinterpret_cast<const f32x4*>(p);
+          if (g.scale) {
+            const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(s[e], v[e], o[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += v[e];
+          }
+          *reinterpret_cast<f32x4*>(p) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + m * g.ldo + n) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_n, int tiles_m) {
+  using Cfg = GemmCfg;
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_m = wave & 1;
+  // tile order: n fastest inside a run of one XCD -> the A panel (128 rows x K) stays
+  // in that XCD's L2 while the W panels stream through it.
+  const int t = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const int tn = t % tiles_n, tm = t / tiles_n;
+  const int n0 = tn * 128;
+  const int64_t m0 = (int64_t)tm * 128;
+  const int nkc = (g.k + 63) / 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // The tile engine addresses rows as base + row * d: lda == ldw == k is required
+  // (checked on the host); "d" is the row length in elements.
+  u32x4 regs[Cfg::NLOAD];
+  sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, 0, tid);
+  sim_stage_store<Cfg>(regs, lds, tid);
+  __syncthreads();
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nkc)
+      sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, kc + 1, tid);
+    sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
+    if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+    __syncthreads();
+  }
+  gemm_epilogue<EPI>(g, acc, m0, n0, wave_n, wave_m, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Patch embedding: Conv2d(C, D, P, P) as a GEMM whose A operand is gathered from
+// the fp32 NCHW image on the fly (no im2col buffer), P == 16.
+//   k = c*256 + ky*16 + kx ; a 64-wide k chunk = 4 image rows of one channel;
+//   a 16-B LDS slot = 8 consecutive pixels of one row (32 B of fp32 source).
+// ---------------------------------------------------------------------------
+struct PatchArgs {
+  const float* img;
+  const _Float16* w;
+  const float* bias;
+  const float* pos;
+  float* tok;
+  int64_t b;
+  int c, h, w_px, gh, gw, d;
+  float pos_mult;
+};
+
+__global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles_n, int tiles_m) {
+  using Cfg = GemmCfg;
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_m = wave & 1;
+  const int t = xcd_remap(blockIdx.x, tiles_n * tiles_m);
+  const int tn = t % tiles_n, tm = t / tiles_n;
+  const int n0 = tn * 128;
+  const int64_t m0 = (int64_t)tm * 128;
+  const int np = p.gh * p.gw;
+  const int64_t mtot = p.b * np;
+  const int kdim = p.c * 256;
+  const int nkc = kdim / 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  u32x4 regs[Cfg::NLOAD];
+  auto load = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < Cfg::NLOAD; ++i) {
+      const int slot = tid + 256 * i;
+      const int row = slot >> 3, chunk = slot & 7;
+      const int k0 = kc * 64 + chunk * 8;
+      if (row < Cfg::GM) {
+        int nr = n0 + row;
+        nr = nr > p.d - 1 ? p.d - 1 : nr;
+        regs[i] = *reinterpret_cast<const u32x4*>(p.w + (int64_t)nr * kdim + k0);
+      } else {
+        int64_t m = m0 + (row - Cfg::GM);
+        m = m > mtot - 1 ? mtot - 1 : m;
+        const int64_t bi = m / np;
+        const int pi = (int)(m % np);
+        const int py = pi / p.gw, px = pi % p.gw;
+        const int c = k0 >> 8, ky = (k0 >> 4) & 15, kx = k0 & 15;
+        const float* src = p.img + ((bi * p.c + c) * p.h + (py * 16 + ky)) * (int64_t)p.w_px + px * 16 + kx;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (_Float16)lo[e];
+          v[4 + e] = (_Float16)hi[e];
+        }
+        regs[i] = __builtin_bit_cast(u32x4, v);
+      }
+    }
+  };
+  load(0);
+  sim_stage_store<Cfg>(regs, lds, tid);
+  __syncthreads();
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nkc) load(kc + 1);
+    sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
+    if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+    __syncthreads();
+  }
+  // epilogue: tok[b][1 + p][n] = acc + bias[n] + pos_mult * pos[1 + p][n]
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int64_t m = m0 + wave_m * 64 + mt * 32 + r;
+    if (m >= mtot) continue;
+    const int64_t bi = m / np;
+    const int pi = (int)(m % np);
+    float* orow = p.tok + (bi * (np + 1) + 1 + pi) * (int64_t)p.d;
+    const float* prow = p.pos + (int64_t)(1 + pi) * p.d;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const int n = n0 + wave_n * 64 + nt * 32 + 8 * grp + 4 * h;
+        if (n >= p.d) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(prow + n);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * grp + e] + b[e] + p.pos_mult * ps[e];
+        *reinterpret_cast<f32x4*>(orow + n) = v;
+      }
+    }
+  }
+}
+
+__global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                               float pos_mult, int64_t b, int t, int d, float* __restrict__ tok) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * d) return;
+  const int64_t bi = i / d;
+  const int n = (int)(i % d);
+  tok[bi * t * (int64_t)d + n] = cls[n] + pos_mult * pos[n];
+}
+
+template <int EPI>
+void launch_gemm(const GemmArgs& g, hipStream_t st) {
+  const int tiles_n = (int)hcir_cdiv(g.n, 128), tiles_m = (int)hcir_cdiv(g.m, 128);
+  hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3(tiles_n * tiles_m), dim3(256), 0, st, g, tiles_n,
+                     tiles_m);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                  const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, void* out,
+                  int64_t ldo, void* stream) {
+  if (!a || !w || !out || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
+  if ((k & 7) || (n & 7) || lda != k || ldw != k || ldo < n || (ldo & 3)) return HCIR_ERR_INVALID;
+  if ((epilogue == HCIR_EPI_AFFINE_RELU_F16 || epilogue == HCIR_EPI_AFFINE_F32) && !scale)
+    return HCIR_ERR_INVALID;
+  if (hcir_cdiv(m, 128) * hcir_cdiv(n, 128) > 0x7fffffff) return HCIR_ERR_INVALID;
+  GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
+             lda, ldw, ldo, n, k};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (epilogue) {
+    case HCIR_EPI_BIAS_F16: launch_gemm<HCIR_EPI_BIAS_F16>(g, st); break;
+    case HCIR_EPI_BIAS_GELU_F16: launch_gemm<HCIR_EPI_BIAS_GELU_F16>(g, st); break;
+    case HCIR_EPI_BIAS_RESID_F32: launch_gemm<HCIR_EPI_BIAS_RESID_F32>(g, st); break;
+    case HCIR_EPI_BIAS_F32: launch_gemm<HCIR_EPI_BIAS_F32>(g, st); break;
+    case HCIR_EPI_AFFINE_RELU_F16: launch_gemm<HCIR_EPI_AFFINE_RELU_F16>(g, st); break;
+    case HCIR_EPI_AFFINE_F32: launch_gemm<HCIR_EPI_AFFINE_F32>(g, st); break;
+    default: return HCIR_ERR_UNSUPPORTED;
+  }
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px, int32_t p,
+                     const void* w_f16, const float* bias, const float* cls, const float* pos,
+                     float pos_mult, int32_t d, float* tok, void* stream) {
+  if (!img || !w_f16 || !bias || !cls || !pos || !tok || b <= 0) return HCIR_ERR_INVALID;
+  if (p != 16) return HCIR_ERR_UNSUPPORTED;  // ViT-*/16 only (ViT-L/14: DESIGN.md "next")
+  if (c <= 0 || h % 16 || w_px % 16 || (d & 7)) return HCIR_ERR_INVALID;
+  PatchArgs a{img, static_cast<const _Float16*>(w_f16), bias, pos, tok, b, c, h, w_px, h / 16,
+              w_px / 16, d, pos_mult};
+  const int np = a.gh * a.gw;
+  const int tiles_n = (int)hcir_cdiv(d, 128), tiles_m = (int)hcir_cdiv(b * np, 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n,
+                     tiles_m);
+  HCIR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cls_row_kernel, dim3((unsigned)hcir_cdiv(b * d, 256)), dim3(256), 0, st, cls,
+                     pos, pos_mult, b, np + 1, d, tok);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""hcir.main_backbone — HSimCLR model classes with the reference's constructor
+signatures (HP/src/main_backbone.py:528-637), backed by the MI355X hot path.
+
+  ViTWrapper(weights=None)             HP/src/main_backbone.py:528-563 (second definition,
+                                       the one that wins at call time)
+  SHAM2(model="resnet18")              HP/src/main_backbone.py:565-637
+  SimCLRProjectionHead(in, hid, out)   lightly.models.modules (keys layers.{0,1,3,4})
+
+ViT compute goes through hcir.vit_engine -> libhcir.so (hand-written HIP);
+ResNet trunks are PyTorch-ROCm modules.  The ViT path has no CPU
+fallback and, in this round, no backward: calling it with autograd enabled on
+parameters that require grad raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import HcirError, check
+from . import _tv_resnet, _tv_vit
+from .vit_engine import EngineCache, VitLayer, VitSpec
+
+# The reference adds the positional embedding in ViTWrapper.forward AND again inside
+# torchvision's Encoder.forward (same Parameter): embeddings are LN(blocks(x + 2*pos)).
+# Reproduced on purpose so reference checkpoints give identical embeddings
+# (HP/src/main_backbone.py:537,551,554).
+POS_EMBED_MULT = 2.0
+
+
+def deactivate_requires_grad(module: nn.Module) -> None:
+    """lightly.models.utils.deactivate_requires_grad."""
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+class SimCLRProjectionHead(nn.Module):
+    """lightly SimCLRProjectionHead(input_dim, hidden_dim, output_dim), num_layers=2:
+    Linear(no bias) -> BatchNorm1d -> ReLU -> Linear(no bias) -> BatchNorm1d
+    (state-dict keys layers.0.weight, layers.1.*, layers.3.weight, layers.4.*)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim, bias=False), nn.BatchNorm1d(hidden_dim), nn.ReLU(),
+            nn.Linear(hidden_dim, output_dim, bias=False), nn.BatchNorm1d(output_dim))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.layers(x)
+
+    # eval-mode forward on the HIP device: two GEMMs with the BatchNorm folded into the
+    # epilogue (scale = w / sqrt(var + eps), shift = b - mean * scale)
+    def forward_hip(self, x16: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("projection head in train mode (batch statistics + backward) "
+                                      "is not on the HIP path yet")
+        L = _lib.lib()
+        lin0, bn0, _, lin1, bn1 = self.layers
+        dev = x16.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+
+        def fold(bn):
+            s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            return s, (bn.bias - bn.running_mean * s).float().contiguous()
+
+        s0, b0 = fold(bn0)
+        s1, b1 = fold(bn1)
+        w0 = lin0.weight.detach().half().contiguous()
+        w1 = lin1.weight.detach().half().contiguous()
+        m, k0 = x16.shape
+        hid = torch.empty((m, w0.shape[0]), dtype=torch.float16, device=dev)
+        out = torch.empty((m, w1.shape[0]), dtype=torch.float32, device=dev)
+        check(L.hcir_gemm_f16(x16.data_ptr(), k0, w0.data_ptr(), k0, b0.data_ptr(), s0.data_ptr(), m,
+                              w0.shape[0], k0, _lib.EPI_AFFINE_RELU_F16, hid.data_ptr(), w0.shape[0], st),
+              "hcir_gemm_f16(head0)")
+        check(L.hcir_gemm_f16(hid.data_ptr(), w0.shape[0], w1.data_ptr(), w0.shape[0], b1.data_ptr(),
+                              s1.data_ptr(), m, w1.shape[0], w0.shape[0], _lib.EPI_AFFINE_F32,
+                              out.data_ptr(), w1.shape[0], st), "hcir_gemm_f16(head1)")
+        return out
+
+
+class ViTWrapper(nn.Module):
+    """torchvision vit_b_16 without its head, as wrapped by the reference.
+
+    forward(x) -> (cls_token [B,768], pooled_patches [B,768]) where both come from
+    ln(encoder_blocks(conv_proj(x) ++ cls + 2 * pos_embedding)).
+    """
+
+    def __init__(self, weights=None):
+        super().__init__()
+        vit = _tv_vit.vit_b_16(weights=weights)
+        self.conv_proj = vit.conv_proj
+        self.encoder = vit.encoder
+        self.cls_token = vit.class_token
+        self.pos_embedding = vit.encoder.pos_embedding
+        self._num_heads = vit.num_heads
+        self._cache = EngineCache()
+
+    # -- HIP engine ------------------------------------------------------------
+    def _spec(self) -> VitSpec:
+        layers = []
+        for blk in self.encoder.layers:
+            mha = blk.self_attention
+            layers.append(VitLayer(
+                ln1_w=blk.ln_1.weight, ln1_b=blk.ln_1.bias,
+                qkv_w=mha.in_proj_weight, qkv_b=mha.in_proj_bias,
+                proj_w=mha.out_proj.weight, proj_b=mha.out_proj.bias,
+                ln2_w=blk.ln_2.weight, ln2_b=blk.ln_2.bias,
+                fc1_w=blk.mlp[0].weight, fc1_b=blk.mlp[0].bias,
+                fc2_w=blk.mlp[3].weight, fc2_b=blk.mlp[3].bias))
+        return VitSpec(patch=16, dim=self.conv_proj.out_channels, heads=self._num_heads, eps=1e-6,
+                       pos_mult=POS_EMBED_MULT, conv_w=self.conv_proj.weight, conv_b=self.conv_proj.bias,
+                       cls=self.cls_token, pos=self.pos_embedding, layers=layers,
+                       final_ln_w=self.encoder.ln.weight, final_ln_b=self.encoder.ln.bias)
+
+    def engine(self, device: torch.device):
+        return self._cache.get(list(self.parameters()), self._spec, device)
+
+    def _check_no_grad(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the HIP ViT path is forward-only this round: wrap the call in torch.no_grad() "
+                "(training backward is SURVEY.md §8f rank 3)")
+
+    def forward(self, x: torch.Tensor):
+        self._check_no_grad()
+        eng = self.engine(x.device)
+        tok = eng.forward_tokens(x)
+        cls_token = eng.cls_embedding(tok, final_norm=True, l2_normalize=False)
+        pooled_patches = eng.patch_mean(tok, final_norm=True)
+        return cls_token, pooled_patches
+
+    def forward_cls(self, x: torch.Tensor, l2_normalize: bool = False, want_f16: bool = False):
+        """CLS embedding only (what SHAM2.extract_features consumes); optionally fused
+        F.normalize and an fp16 copy for the similarity scan."""
+        self._check_no_grad()
+        eng = self.engine(x.device)
+        tok = eng.forward_tokens(x)
+        return eng.cls_embedding(tok, final_norm=True, l2_normalize=l2_normalize, want_f16=want_f16)
+
+
+class SHAM2(nn.Module):
+    """HSimCLR model (README 'HSimCLR' == class SHAM2, HP/src/main_backbone.py:565-637)."""
+
+    def __init__(self, model="resnet18"):
+        super().__init__()
+        self.model = model
+        print("Using backbone:", self.model)
+
+        if model == "resnet18":
+            backbone = _tv_resnet.resnet18(weights=None)
+            self.backbone = nn.Sequential(*list(backbone.children())[:-1])
+            proj_input_dim, output_dim = 512, 128
+        elif model == "resnet50":
+            backbone = _tv_resnet.resnet50(weights=None)
+            self.backbone = nn.Sequential(*list(backbone.children())[:-1])
+            proj_input_dim, output_dim = 2048, 1024
+        elif model == "vit_b_16":
+            self.backbone = ViTWrapper(weights=None)
+            proj_input_dim, output_dim = 768, 512
+        else:
+            raise ValueError(f"Unsupported model: {model}")
+
+        self.projection_head = SimCLRProjectionHead(proj_input_dim, proj_input_dim, output_dim)
+
+        # momentum encoder
+        self.backbone_momentum = copy.deepcopy(self.backbone)
+        self.projection_head_momentum = copy.deepcopy(self.projection_head)
+        deactivate_requires_grad(self.backbone_momentum)
+        deactivate_requires_grad(self.projection_head_momentum)
+
+    def _vit_project(self, backbone, head, x):
+        if head.training:
+            raise NotImplementedError("SHAM2.forward in train mode through the HIP ViT is not built "
+                                      "yet (SURVEY.md §8f rank 3); call .eval() and torch.no_grad()")
+        _, cls16 = backbone.forward_cls(x, l2_normalize=False, want_f16=True)
+        return head.forward_hip(cls16)
+
+    def forward(self, x):
+        if "vit" in self.model:
+            return self._vit_project(self.backbone, self.projection_head, x)
+        x = self.backbone(x).flatten(start_dim=1)
+        return self.projection_head(x)
+
+    @torch.no_grad()
+    def forward_momentum(self, x):
+        if "vit" in self.model:
+            return self._vit_project(self.backbone_momentum, self.projection_head_momentum, x)
+        x = self.backbone_momentum(x).flatten(start_dim=1)
+        return self.projection_head_momentum(x)
+
+    def extract_features(self, x):
+        if "vit" in self.model:
+            return self.backbone.forward_cls(x)
+        return self.backbone(x).flatten(start_dim=1)
+
+    @torch.no_grad()
+    def extract_features_ema(self, x):
+        if "vit" in self.model:
+            return self.backbone_momentum.forward_cls(x)
+        return self.backbone_momentum(x).flatten(start_dim=1)

@@ -1,0 +1,200 @@
+"""hcir.vit_engine — the ViT forward on MI355X through libhcir (C ABI, HIP kernels).
+
+A `VitSpec` is the architecture-neutral description both model families
+(torchvision-layout ViTWrapper, timm-layout models_vit.VisionTransformer) reduce to.
+`VitEngine.forward_tokens` runs
+    patch_embed (+cls, +pos)  ->  depth x [ LN -> qkv GEMM -> fused attention ->
+    proj GEMM (+residual) -> LN -> fc1 GEMM (+GELU) -> fc2 GEMM (+residual) ]
+with fp16 MFMA operands, fp32 accumulation and an fp32 residual stream, entirely in
+device buffers the engine owns (re-used across calls).  There is no CPU path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import HcirError, check
+
+
+@dataclass
+class VitLayer:
+    ln1_w: torch.Tensor
+    ln1_b: torch.Tensor
+    qkv_w: torch.Tensor   # [3D, D]
+    qkv_b: Optional[torch.Tensor]
+    proj_w: torch.Tensor  # [D, D]
+    proj_b: torch.Tensor
+    ln2_w: torch.Tensor
+    ln2_b: torch.Tensor
+    fc1_w: torch.Tensor   # [mlp, D]
+    fc1_b: torch.Tensor
+    fc2_w: torch.Tensor   # [D, mlp]
+    fc2_b: torch.Tensor
+    ls1: Optional[torch.Tensor] = None  # LayerScale gamma
+    ls2: Optional[torch.Tensor] = None
+
+
+@dataclass
+class VitSpec:
+    patch: int
+    dim: int
+    heads: int
+    eps: float
+    pos_mult: float           # 2.0 for the reference's ViTWrapper (double positional add)
+    conv_w: torch.Tensor      # [D, 3, P, P]
+    conv_b: torch.Tensor
+    cls: torch.Tensor         # [1, 1, D]
+    pos: torch.Tensor         # [1, T, D]
+    layers: List[VitLayer] = field(default_factory=list)
+    final_ln_w: Optional[torch.Tensor] = None
+    final_ln_b: Optional[torch.Tensor] = None
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _f16(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float16).contiguous()
+
+
+class _DevLayer:
+    def __init__(self, l: VitLayer, dev):
+        self.ln1_w, self.ln1_b = _f32(l.ln1_w, dev), _f32(l.ln1_b, dev)
+        self.ln2_w, self.ln2_b = _f32(l.ln2_w, dev), _f32(l.ln2_b, dev)
+        self.qkv_w, self.proj_w = _f16(l.qkv_w, dev), _f16(l.proj_w, dev)
+        self.fc1_w, self.fc2_w = _f16(l.fc1_w, dev), _f16(l.fc2_w, dev)
+        self.qkv_b = None if l.qkv_b is None else _f32(l.qkv_b, dev)
+        self.proj_b, self.fc1_b, self.fc2_b = _f32(l.proj_b, dev), _f32(l.fc1_b, dev), _f32(l.fc2_b, dev)
+        self.ls1 = None if l.ls1 is None else _f32(l.ls1, dev)
+        self.ls2 = None if l.ls2 is None else _f32(l.ls2, dev)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class VitEngine:
+    """Device-resident fp16 weights + work buffers for one ViT; forward via the C ABI."""
+
+    def __init__(self, spec: VitSpec, device: torch.device):
+        if device.type != "cuda":
+            raise HcirError(f"VitEngine needs a HIP device, got {device} (no CPU fallback)")
+        if spec.patch != 16:
+            raise HcirError("hcir_patch_embed supports patch 16 (ViT-*/16) in this build")
+        if spec.dim % spec.heads or spec.dim // spec.heads != 64:
+            raise HcirError("hcir_attn_fwd supports head_dim 64")
+        self.L = _lib.lib()
+        self.device = device
+        self.dim, self.heads, self.eps, self.pos_mult = spec.dim, spec.heads, float(spec.eps), float(spec.pos_mult)
+        self.conv_w = _f16(spec.conv_w.reshape(spec.dim, -1), device)
+        self.conv_b = _f32(spec.conv_b, device)
+        self.cls = _f32(spec.cls.reshape(-1), device)
+        self.pos = _f32(spec.pos.reshape(-1, spec.dim), device)
+        self.layers = [_DevLayer(l, device) for l in spec.layers]
+        self.mlp = spec.layers[0].fc1_w.shape[0] if spec.layers else 4 * spec.dim
+        self.fln_w = None if spec.final_ln_w is None else _f32(spec.final_ln_w, device)
+        self.fln_b = None if spec.final_ln_b is None else _f32(spec.final_ln_b, device)
+        self._bufs = {}
+
+    # -- buffers ---------------------------------------------------------------
+    def _buffers(self, b: int, t: int):
+        key = (b, t)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            m, d, dev = b * t, self.dim, self.device
+            bufs = dict(
+                tok=torch.empty((b, t, d), dtype=torch.float32, device=dev),
+                ln=torch.empty((m, d), dtype=torch.float16, device=dev),
+                qkv=torch.empty((m, 3 * d), dtype=torch.float16, device=dev),
+                att=torch.empty((m, d), dtype=torch.float16, device=dev),
+                hid=torch.empty((m, self.mlp), dtype=torch.float16, device=dev),
+            )
+            self._bufs = {key: bufs}  # keep one shape resident
+        return bufs
+
+    # -- forward ---------------------------------------------------------------
+    def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 [B,3,H,W] on the HIP device -> fp32 token buffer [B,T,D] (engine-owned)."""
+        if not x.is_cuda:
+            raise HcirError(f"input is on {x.device}; the hcir ViT runs on a HIP device only")
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        b, c, hh, ww = x.shape
+        if hh % 16 or ww % 16:
+            raise HcirError("image sides must be multiples of the patch size")
+        t = (hh // 16) * (ww // 16) + 1
+        if t != self.pos.shape[0]:
+            raise HcirError(f"image gives {t} tokens but pos_embedding has {self.pos.shape[0]}")
+        L, d, m = self.L, self.dim, b * t
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        w = self._buffers(b, t)
+        tok, ln, qkv, att, hid = w["tok"], w["ln"], w["qkv"], w["att"], w["hid"]
+        check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, 16, self.conv_w.data_ptr(),
+                                 self.conv_b.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(),
+                                 self.pos_mult, d, tok.data_ptr(), st), "hcir_patch_embed")
+        scale = (d // self.heads) ** -0.5
+        for l in self.layers:
+            check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
+                                       self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+            check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
+                                  _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d, st), "hcir_gemm_f16(qkv)")
+            check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale,
+                                  att.data_ptr(), st), "hcir_attn_fwd")
+            check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
+                                  m, d, d, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
+            check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln2_w.data_ptr(), l.ln2_b.data_ptr(),
+                                       self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+            check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
+                                  self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
+                  "hcir_gemm_f16(fc1)")
+            check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
+                                  _p(l.ls2), m, d, self.mlp, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st),
+                  "hcir_gemm_f16(fc2)")
+        return tok
+
+    def cls_embedding(self, tok: torch.Tensor, final_norm: bool, l2_normalize: bool,
+                      want_f16: bool = False):
+        """CLS row of the token buffer, through the final LayerNorm (if the model has one)
+        and optionally F.normalize; fp32 [B,D] (and an fp16 copy for the similarity scan)."""
+        b, t, d = tok.shape
+        st = torch.cuda.current_stream(tok.device).cuda_stream
+        e32 = torch.empty((b, d), dtype=torch.float32, device=tok.device)
+        e16 = torch.empty((b, d), dtype=torch.float16, device=tok.device) if want_f16 else None
+        g = self.fln_w if final_norm else None
+        bb = self.fln_b if final_norm else None
+        if final_norm and g is None:
+            raise HcirError("model has no final LayerNorm")
+        check(self.L.hcir_cls_head(tok.data_ptr(), b, t, d, _p(g), _p(bb), self.eps, int(l2_normalize),
+                                   e32.data_ptr(), _p(e16), st), "hcir_cls_head")
+        return (e32, e16) if want_f16 else e32
+
+    def patch_mean(self, tok: torch.Tensor, final_norm: bool) -> torch.Tensor:
+        b, t, d = tok.shape
+        st = torch.cuda.current_stream(tok.device).cuda_stream
+        out = torch.empty((b, d), dtype=torch.float32, device=tok.device)
+        g = self.fln_w if final_norm else None
+        bb = self.fln_b if final_norm else None
+        check(self.L.hcir_patch_mean(tok.data_ptr(), b, t, d, _p(g), _p(bb), self.eps, out.data_ptr(), st),
+              "hcir_patch_mean")
+        return out
+
+
+class EngineCache:
+    """Builds the VitEngine lazily and rebuilds it when parameters or device change
+    (load_state_dict / .to() bump tensor._version or replace .data)."""
+
+    def __init__(self):
+        self._engine: Optional[VitEngine] = None
+        self._key = None
+
+    def get(self, params, make_spec, device: torch.device) -> VitEngine:
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._engine is None or key != self._key:
+            self._engine = VitEngine(make_spec(), device)
+            self._key = key
+        return self._engine

@@ -1,0 +1,204 @@
+"""GPU parity of the ViT kernels (C ABI) and of the end-to-end embedding.
+
+Floating-point path: fp16 MFMA operands, fp32 accumulate.  Tolerances are written in
+each test; the end-to-end bar is north_star's: 1 - cos(embedding, oracle) <= 1e-3.
+Per-kernel references are plain torch fp32 of the same op on the same (fp16-rounded)
+operands; the end-to-end reference is oracle.vit (fp32, un-rounded weights).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vit as ovit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L(hcir_built):
+    assert torch.cuda.is_available()
+    return hcir_built
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (197 * 3, 768, 768), (1000, 2304, 768),
+                                   (333, 3072, 768), (260, 768, 3072), (5, 8, 8), (130, 136, 72)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(L, m, n, k, epi):
+    from hcir import _lib
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k + epi)
+    a = (torch.randn(m, k, generator=g) * 0.5).half()
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).half()
+    bias = torch.randn(n, generator=g)
+    scale = torch.rand(n, generator=g) + 0.5
+    ref = a.float() @ w.float().t() + bias
+    ad, wd, bd, sd_ = a.cuda(), w.cuda(), bias.cuda(), scale.cuda()
+    if epi in (0, 1):
+        out = torch.empty(m, n, dtype=torch.float16, device="cuda")
+        if epi == 1:
+            ref = F.gelu(ref)
+        sp = None
+    elif epi == 2:
+        resid = torch.randn(m, n, generator=g)
+        out = resid.cuda()
+        ref = resid + scale * ref
+        sp = sd_.data_ptr()
+    else:
+        out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+        sp = None
+    st = L.hcir_gemm_f16(ad.data_ptr(), k, wd.data_ptr(), k, bd.data_ptr(), sp, m, n, k, epi,
+                         out.data_ptr(), n, _st())
+    assert st == 0
+    got = out.float().cpu()
+    # fp32 accumulate of exact fp16 products: error is fp32 summation + (for fp16 outputs) one rounding
+    tol = 2e-3 if epi in (0, 1) else 1e-4
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=tol * max(1.0, ref.abs().max().item()), rtol=0)
+
+
+def test_gemm_affine_epilogues(L):
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 70, 512, 768
+    a = torch.randn(m, k, generator=g).half()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).half()
+    s, b = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    ref = (a.float() @ w.float().t()) * s + b
+    o16 = torch.empty(m, n, dtype=torch.float16, device="cuda")
+    o32 = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    args = (a.cuda(), w.cuda(), b.cuda(), s.cuda())
+    assert L.hcir_gemm_f16(args[0].data_ptr(), k, args[1].data_ptr(), k, args[2].data_ptr(), args[3].data_ptr(),
+                           m, n, k, 4, o16.data_ptr(), n, _st()) == 0
+    assert L.hcir_gemm_f16(args[0].data_ptr(), k, args[1].data_ptr(), k, args[2].data_ptr(), args[3].data_ptr(),
+                           m, n, k, 5, o32.data_ptr(), n, _st()) == 0
+    np.testing.assert_allclose(o32.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(o16.float().cpu().numpy(), F.relu(ref).numpy(), atol=4e-3, rtol=0)
+
+
+@pytest.mark.parametrize("rows,d", [(197 * 2, 768), (7, 1024), (33, 2048), (5, 64)])
+def test_layernorm(L, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 3 + 0.7
+    w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    ref = F.layer_norm(x, (d,), w, b, 1e-6)
+    y = torch.empty(rows, d, dtype=torch.float16, device="cuda")
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    assert L.hcir_layernorm_f16(xd.data_ptr(), rows, d, d, wd.data_ptr(), bd.data_ptr(), 1e-6,
+                                y.data_ptr(), d, _st()) == 0
+    # fp16 output rounding: 2^-11 relative
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=2e-3 * ref.abs().max().item(), rtol=0)
+
+
+@pytest.mark.parametrize("b,t,h", [(2, 197, 12), (1, 17, 2), (3, 64, 4), (2, 257, 16), (1, 33, 1), (1, 288, 2)])
+def test_attention(L, b, t, h):
+    g = torch.Generator().manual_seed(b * 100 + t + h)
+    hd = 64
+    qkv = (torch.randn(b, t, 3, h, hd, generator=g) * 1.5).half()
+    q, k, v = [qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]  # [b,h,t,hd]
+    scale = hd ** -0.5
+    ref = torch.softmax((q * scale) @ k.transpose(-2, -1), -1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(b, t, h * hd)
+    out = torch.empty(b, t, h * hd, dtype=torch.float16, device="cuda")
+    qd = qkv.cuda()
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, scale, out.data_ptr(), _st()) == 0
+    # P is rounded to fp16 before PV (2^-11 relative per term), output rounded to fp16
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
+
+
+def test_attention_spiked_row(L):
+    """One key dominates one query (softmax near one-hot) and large negative scores elsewhere."""
+    b, t, h, hd = 1, 197, 1, 64
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(b, t, 3, h, hd, generator=g).half()
+    qkv[0, 5, 0] = qkv[0, 150, 1] * 6.0     # q5 aligned with k150
+    q, k, v = [qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]
+    ref = (torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), -1) @ v).permute(0, 2, 1, 3).reshape(b, t, hd)
+    out = torch.empty(b, t, hd, dtype=torch.float16, device="cuda")
+    qd = qkv.cuda()
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, out.data_ptr(), _st()) == 0
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
+
+
+@pytest.mark.parametrize("b,pos_mult", [(3, 2.0), (1, 1.0)])
+def test_patch_embed(L, b, pos_mult):
+    g = torch.Generator().manual_seed(b)
+    d = 768
+    img = torch.randn(b, 3, 224, 224, generator=g)
+    w = (torch.randn(d, 3, 16, 16, generator=g) * 0.03)
+    bias, cls, pos = torch.randn(d, generator=g), torch.randn(d, generator=g), torch.randn(197, d, generator=g)
+    w16 = w.half()
+    ref = F.conv2d(img.half().float(), w16.float(), bias, stride=16).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(b, 1, d), ref], 1) + pos_mult * pos
+    tok = torch.empty(b, 197, d, device="cuda")
+    args = [t_.cuda() for t_ in (img, w16.reshape(d, -1).contiguous(), bias, cls, pos)]
+    assert L.hcir_patch_embed(args[0].data_ptr(), b, 3, 224, 224, 16, args[1].data_ptr(), args[2].data_ptr(),
+                              args[3].data_ptr(), args[4].data_ptr(), pos_mult, d, tok.data_ptr(), _st()) == 0
+    np.testing.assert_allclose(tok.cpu().numpy(), ref.numpy(), atol=2e-4 * ref.abs().max().item(), rtol=0)
+
+
+def _randomize(model, seed):
+    """Perturb every parameter / buffer so that no bias, LN weight or BN statistic is trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+            if not p.dtype.is_floating_point:
+                continue
+            if "running_var" in name:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif name.endswith("ln_1.weight") or name.endswith("ln_2.weight") or name.endswith("ln.weight") \
+                    or "norm" in name and name.endswith("weight") or ".1.weight" in name or ".4.weight" in name:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.dim() <= 1 or "cls_token" in name or "pos_emb" in name or "pos_embed" in name:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+
+
+def _cos_err(a, b):
+    return (1.0 - F.cosine_similarity(a.double(), b.double(), dim=1)).abs().max().item()
+
+
+def test_vit_b16_embedding_vs_oracle(L):
+    """SHAM2('vit_b_16').extract_features + F.normalize vs the fp32 oracle: <= 1e-3 cosine."""
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(42)
+    model = SHAM2("vit_b_16").eval()
+    _randomize(model, 1)
+    # the two aliases of pos_embedding / must stay tied after perturbation
+    assert model.backbone.pos_embedding.data_ptr() == model.backbone.encoder.pos_embedding.data_ptr()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    ref = ovit.sham2_extract_features(sd, x, "vit_b_16")
+    model = model.cuda()
+    with torch.no_grad():
+        got = model.extract_features(x.cuda()).cpu()
+        cls, pooled = model.backbone(x.cuda())
+        z = model(x.cuda()).cpu()
+        zm = model.forward_momentum(x.cuda()).cpu()
+    assert _cos_err(got, ref) <= 1e-3
+    ref_cls, ref_pool = ovit.vitwrapper_forward(sd, x, "backbone.")
+    assert _cos_err(cls.cpu(), ref_cls) <= 1e-3
+    assert _cos_err(pooled.cpu(), ref_pool) <= 1e-3
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-2 * ref.abs().max().item(), rtol=0)
+    # projection heads (eval-mode BN folded into the GEMM epilogue)
+    ref_z = ovit.projection_head_forward(sd, ref_cls, "projection_head.")
+    assert _cos_err(z, ref_z) <= 1e-3
+    ref_m = ovit.projection_head_forward(sd, ovit.vitwrapper_forward(sd, x, "backbone_momentum.")[0],
+                                         "projection_head_momentum.")
+    assert _cos_err(zm, ref_m) <= 1e-3
+
+
+def test_vit_requires_no_grad_and_device(L):
+    from hcir import HcirError
+    from hcir.main_backbone import SHAM2
+    model = SHAM2("vit_b_16").eval()
+    x = torch.randn(1, 3, 224, 224)
+    with torch.no_grad(), pytest.raises(HcirError):
+        model.extract_features(x)  # CPU tensor: no fallback
+    model = model.cuda()
+    with pytest.raises(NotImplementedError):
+        model.extract_features(x.cuda())  # autograd on: backward is not built
+    with pytest.raises(ValueError):
+        SHAM2("vgg16")

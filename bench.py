@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py — query-images/sec of the retrieval hot path on MI355X.
+
+One step = one batch of synthetic 224x224 query crops per rank through
+    ViT-B/16 embed (HSimCLR ViTWrapper numerics) -> L2-normalise
+    -> [N>1: RCCL all-gather of the query embeddings]
+    -> hcir_sim_topk of ALL queries against this rank's shard of a 1M x 768 gallery
+    -> [N>1: RCCL all-gather of per-shard top-10 + hcir_topk_merge]
+Inputs (query crops, gallery shard) are resident in HBM before the timed region.
+`value` = total query images of all ranks / wall time (max over ranks).
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
+prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "hair-centric-image-retrieval_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+METRIC = "query-images/sec (embed+top-10) ViT-B/16 vs 1M gallery, 1/2/4/8 GPU"
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA (exact fp32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="query images per rank per step")
+    ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (sharded over ranks)")
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--gallery-dtype", default="f32", choices=["f32", "f16"],
+                    help="f32 = exact fp32 scores (top-k bit-identical to the oracle); f16 = half the bytes")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="query images in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def vit_flops(b, t=197, d=768, mlp=3072, heads=12, layers=12):
+    m = b * t
+    gemm = {"gemm_qkv": 2 * m * 3 * d * d, "gemm_proj": 2 * m * d * d, "gemm_fc1": 2 * m * mlp * d,
+            "gemm_fc2": 2 * m * d * mlp}
+    gemm = {k: v * layers for k, v in gemm.items()}
+    attn = 4 * b * heads * t * t * (d // heads) * layers
+    patch = 2 * b * (t - 1) * d * d
+    return gemm, attn, patch
+
+
+def cpu_baseline(args, sd, nthreads):
+    """Reference-semantics CPU path on a bounded sample: oracle ViT-B/16 forward (torch CPU
+    fp32, all host cores) + sklearn KNeighborsClassifier(metric='cosine').kneighbors against
+    a gallery slice, scaled linearly to the full gallery."""
+    import numpy as np
+    from oracle import vit as ovit
+    torch.set_num_threads(nthreads)
+    n = args.cpu_sample
+    x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
+    emb = ovit.classifier_embed(sd, x, "vit_b_16")
+    t_embed = time.perf_counter() - t0
+    slice_rows = min(args.gallery, 200_000)
+    g = F.normalize(torch.randn(slice_rows, 768, generator=torch.Generator().manual_seed(1000)), dim=1).numpy()
+    kind = "port"
+    t0 = time.perf_counter()
+    try:
+        from sklearn.neighbors import KNeighborsClassifier
+        knn = KNeighborsClassifier(n_neighbors=args.topk, metric="cosine")
+        knn.fit(g, np.zeros(slice_rows, dtype=np.int64))
+        knn.kneighbors(emb.numpy())
+        knn_impl = "sklearn KNeighborsClassifier(metric=cosine).kneighbors"
+    except ImportError:
+        from oracle import knn as oknn
+        oknn.cosine_topk(emb.numpy(), g, args.topk)
+        knn_impl = "oracle/knn_oracle.c"
+    t_knn = (time.perf_counter() - t0) * (args.gallery / slice_rows)
+    return {
+        "value": n / (t_embed + t_knn), "unit": "query-images/sec", "cores": nthreads, "kind": kind,
+        "sample": (f"{n} images: oracle.vit ViT-B/16 fp32 forward on torch CPU ({t_embed:.2f}s) + {knn_impl} "
+                   f"top-{args.topk} over a {slice_rows}-row slice scaled x{args.gallery / slice_rows:.1f} "
+                   f"to {args.gallery} rows ({t_knn:.2f}s)"),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hcir
+    from hcir import ops
+    from hcir.dist import ShardedGallery, shard_bounds
+    from hcir.main_backbone import SHAM2
+    from hcir.profiling import EventProfiler
+    hcir.lib()
+
+    # ---- model: random-init ViT-B/16 of the HSimCLR architecture (no checkpoints offline)
+    torch.manual_seed(42)
+    model = SHAM2("vit_b_16").eval()
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev)
+    vit = model.backbone
+
+    # ---- gallery shard: rows [lo, hi), generated per shard from seed 1000 + rank, L2-normalised
+    lo, hi = shard_bounds(args.gallery, world, rank)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    shard = torch.empty((hi - lo, 768), dtype=torch.float32, device=dev)
+    for s in range(0, hi - lo, 131072):
+        e = min(hi - lo, s + 131072)
+        shard[s:e] = F.normalize(torch.randn((e - s, 768), generator=gen, device=dev), dim=1)
+    gdtype = torch.float32 if args.gallery_dtype == "f32" else torch.float16
+    shard = ops.convert(shard, gdtype)
+    gallery = ShardedGallery(shard, lo)
+
+    # ---- query crops resident in HBM
+    x = torch.randn((args.batch, 3, 224, 224), generator=torch.Generator(device=dev).manual_seed(1 + rank),
+                    device=dev)
+
+    def step(prof=None):
+        with torch.no_grad():
+            e32, e16 = vit.forward_cls(x, l2_normalize=True, want_f16=True)
+            if prof:
+                prof.mark("cls_head")
+            q = e32 if gdtype == torch.float32 else e16
+            q_all = gallery.gather_queries(q)
+            if prof:
+                prof.mark("allgather_q")
+            out = gallery.search(q_all, args.topk)
+            if prof:
+                prof.mark("sim_topk+merge")
+            return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    # ---- per-kernel attribution (same workload, HIP events on the launch stream), after the timed region
+    nprof = 3
+    prof = EventProfiler()
+    eng = vit.engine(dev)
+    eng.prof = prof
+    for _ in range(nprof):
+        prof.start()
+        step(prof)
+    eng.prof = None
+    summ = prof.summary()
+    per_step = {k: v["ms"] / nprof for k, v in summ.items()}
+    calls = {k: v["calls"] // nprof for k, v in summ.items()}
+    # sim_topk alone (scan + merge kernels of hcir_sim_topk), events around the C call
+    with torch.no_grad():
+        e32, e16 = vit.forward_cls(x, l2_normalize=True, want_f16=True)
+        q_all = gallery.gather_queries(e32 if gdtype == torch.float32 else e16)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ops.sim_topk(q_all, shard, args.topk, idx_base=lo)
+        ev[0].record()
+        for _ in range(5):
+            ops.sim_topk(q_all, shard, args.topk, idx_base=lo)
+        ev[1].record()
+        torch.cuda.synchronize()
+        sim_ms = ev[0].elapsed_time(ev[1]) / 5
+
+    if rank == 0:
+        total_imgs = args.batch * world * args.steps
+        gemm_f, attn_f, patch_f = vit_flops(args.batch)
+        gemm_ms = sum(per_step.get(k, 0.0) for k in gemm_f)
+        gemm_tf = sum(gemm_f.values()) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ncalls_gemm = sum(calls.get(k, 0) for k in gemm_f)
+        nq_all = args.batch * world
+        sim_bytes = shard.shape[0] * 768 * shard.element_size() + nq_all * 768 * shard.element_size() \
+            + nq_all * args.topk * 12
+        sim_gbs = sim_bytes / (sim_ms * 1e-3) / 1e9
+        sim_tf = 2.0 * nq_all * shard.shape[0] * 768 / (sim_ms * 1e-3) / 1e12
+        attn_ms = per_step.get("attn", 0.0)
+        out = {
+            "metric": METRIC, "value": total_imgs / elapsed, "unit": "query-images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 (HSimCLR ViTWrapper, random init) embed + top-{args.topk} over "
+                                   f"{args.gallery} x 768 {args.gallery_dtype} gallery row-sharded over {world} GPU(s)",
+                       "query_batch_per_gpu": args.batch, "global_query_batch": nq_all,
+                       "gallery_rows": args.gallery, "gallery_dtype": args.gallery_dtype, "topk": args.topk,
+                       "parallelism": f"gallery-shard{world}+query-dp{world}"},
+            # dominant kernel by time: the fp16 MFMA GEMM (4 per layer x 12 layers per step)
+            "roofline": {"kernel": "gemm_f16_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",
+                         "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": gemm_tf / MFMA_F16_PEAK_TF, "traffic": None,
+                         "launches_per_step": ncalls_gemm, "avg_launch_ms": gemm_ms / max(ncalls_gemm, 1)},
+            "roofline_sim_topk": {"kernel": "sim_topk_scan (+merge)", "bound": "hbm", "achieved": sim_gbs,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS,
+                                  "traffic": None, "ms": sim_ms, "queries": nq_all,
+                                  "mfma_tflops": sim_tf,
+                                  "mfma_frac": sim_tf / (MFMA_F32_PEAK_TF if gdtype == torch.float32 else MFMA_F16_PEAK_TF)},
+            "roofline_attn": {"kernel": "attn_fwd_kernel", "bound": "mfma",
+                              "achieved": attn_f / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
+                              "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": (attn_f / (attn_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if attn_ms else 0.0},
+            "phase_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sd_cpu, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

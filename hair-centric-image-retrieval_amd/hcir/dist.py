@@ -1,0 +1,70 @@
+"""hcir.dist — gallery row-sharding across the GPUs of one node.
+
+The reference is single-GPU with the kNN on the CPU: there is no NCCL
+call pattern to translate.  The sharded search is new capability defined by north_star:
+
+  rank r holds gallery rows [r*N/P, (r+1)*N/P)   (contiguous, idx_base = first row)
+  1. all-gather of the query embeddings   [Q/P, D] per rank   (RCCL over xGMI)
+  2. local hcir_sim_topk of ALL Q queries against the local shard -> (val, idx)[Q, k]
+     with GLOBAL row indices
+  3. all-gather of the per-shard top-k    Q*k*12 B per rank
+  4. hcir_topk_merge of the P lists with the global tie-break (score desc, index asc)
+     -> identical to a single-GPU scan of the whole gallery.
+
+Both payloads are latency-bound (KBs); one process per GPU, torch.distributed
+(backend "nccl" == RCCL on ROCm).  `ops` is injectable so the world_size-2 gloo tests
+can drive the same control flow on CPU with the oracle as the checker's stand-in.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous near-equal split: the first n_rows % world ranks get one extra row."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedGallery:
+    """One rank's shard of an L2-normalised gallery plus the collective search."""
+
+    def __init__(self, shard: torch.Tensor, idx_base: int, group=None, ops=None,
+                 g_inv_norm: Optional[torch.Tensor] = None):
+        if ops is None:
+            from . import ops as _ops  # HIP path; raises if libhcir.so is missing
+            ops = _ops
+        self.ops = ops
+        self.shard = shard
+        self.idx_base = int(idx_base)
+        self.group = group
+        self.g_inv_norm = g_inv_norm
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return q_local
+        out = [torch.empty_like(q_local) for _ in range(self.world)]
+        dist.all_gather(out, q_local.contiguous(), group=self.group)
+        return torch.cat(out, 0)
+
+    def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
+        """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""
+        k_local = min(k, self.shard.shape[0])
+        val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
+                                     g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
+        if k_local < k:  # tiny shard: pad with empty slots
+            pad_v = torch.full((val.shape[0], k - k_local), float("-inf"), dtype=val.dtype, device=val.device)
+            pad_i = torch.full((idx.shape[0], k - k_local), -1, dtype=idx.dtype, device=idx.device)
+            val, idx = torch.cat([val, pad_v], 1), torch.cat([idx, pad_i], 1)
+        if self.world == 1:
+            return val, idx
+        vals = [torch.empty_like(val) for _ in range(self.world)]
+        idxs = [torch.empty_like(idx) for _ in range(self.world)]
+        dist.all_gather(vals, val.contiguous(), group=self.group)
+        dist.all_gather(idxs, idx.contiguous(), group=self.group)
+        return self.ops.topk_merge(torch.stack(vals, 0), torch.stack(idxs, 0), k)

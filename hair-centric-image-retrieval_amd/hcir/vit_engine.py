@@ -99,6 +99,11 @@ class VitEngine:
         self.fln_w = None if spec.final_ln_w is None else _f32(spec.final_ln_w, device)
         self.fln_b = None if spec.final_ln_b is None else _f32(spec.final_ln_b, device)
         self._bufs = {}
+        self.prof = None  # optional hcir.profiling.EventProfiler (per-op HIP events)
+
+    def _mark(self, name: str) -> None:
+        if self.prof is not None:
+            self.prof.mark(name)
 
     # -- buffers ---------------------------------------------------------------
     def _buffers(self, b: int, t: int):
@@ -137,24 +142,32 @@ class VitEngine:
         check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, 16, self.conv_w.data_ptr(),
                                  self.conv_b.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(),
                                  self.pos_mult, d, tok.data_ptr(), st), "hcir_patch_embed")
+        self._mark("patch_embed")
         scale = (d // self.heads) ** -0.5
         for l in self.layers:
             check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
                                        self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+            self._mark("layernorm")
             check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
                                   _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d, st), "hcir_gemm_f16(qkv)")
+            self._mark("gemm_qkv")
             check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale,
                                   att.data_ptr(), st), "hcir_attn_fwd")
+            self._mark("attn")
             check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
                                   m, d, d, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
+            self._mark("gemm_proj")
             check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln2_w.data_ptr(), l.ln2_b.data_ptr(),
                                        self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+            self._mark("layernorm")
             check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
                                   self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
                   "hcir_gemm_f16(fc1)")
+            self._mark("gemm_fc1")
             check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
                                   _p(l.ls2), m, d, self.mlp, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st),
                   "hcir_gemm_f16(fc2)")
+            self._mark("gemm_fc2")
         return tok
 
     def cls_embedding(self, tok: torch.Tensor, final_norm: bool, l2_normalize: bool,

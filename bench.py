@@ -59,6 +59,18 @@ def vit_flops(b, t=197, d=768, mlp=3072, heads=12, layers=12):
     return gemm, attn, patch
 
 
+def host_cores() -> int:
+    """Cores this process may use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, sd, nthreads):
     """Reference-semantics CPU path on a bounded sample: oracle ViT-B/16 forward (torch CPU
     fp32, all host cores) + sklearn KNeighborsClassifier(metric='cosine').kneighbors against
@@ -119,7 +131,9 @@ def main():
 
     # ---- model: random-init ViT-B/16 of the HSimCLR architecture (no checkpoints offline)
     torch.manual_seed(42)
-    model = SHAM2("vit_b_16").eval()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # the reference's ctor prints; keep stdout = one JSON line
+        model = SHAM2("vit_b_16").eval()
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
     vit = model.backbone
@@ -236,7 +250,7 @@ def main():
             "phase_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, sd_cpu, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args, sd_cpu, host_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

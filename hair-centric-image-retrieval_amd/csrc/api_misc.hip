@@ -2,7 +2,8 @@
 #include "common.h"
 
 extern "C" {
-int hcir_version(void) { return 100; }
+int hcir_version(void) {
+  HCIR_ENTER(); return 100; }
 
 const char* hcir_status_string(int status) {
   switch (status) {

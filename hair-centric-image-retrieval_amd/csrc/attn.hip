@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_kernel(AttnArgs a) {
 
 extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
                              float scale, void* out, void* stream) {
+  HCIR_ENTER();
   if (!qkv || !out || b <= 0 || t <= 0 || h <= 0) return HCIR_ERR_INVALID;
   if (hd != 64 || t > 288) return HCIR_ERR_UNSUPPORTED;
   if (b * h > 0x7fffffff) return HCIR_ERR_INVALID;

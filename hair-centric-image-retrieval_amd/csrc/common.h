@@ -17,6 +17,11 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define HCIR_WAVE 64
 
+// hipGetLastError() is sticky per host thread: clear whatever an earlier runtime call of
+// the caller (torch's event queries return hipErrorNotReady, ...) left behind, so that the
+// check after our launch reports only our launch.
+#define HCIR_ENTER() (void)hipGetLastError()
+
 #define HCIR_LAUNCH_CHECK()                         \
   do {                                              \
     if (hipGetLastError() != hipSuccess) return HCIR_ERR_LAUNCH; \

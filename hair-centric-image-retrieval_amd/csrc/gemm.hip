@@ -266,6 +266,7 @@ extern "C" {
 int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
                   const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, void* out,
                   int64_t ldo, void* stream) {
+  HCIR_ENTER();
   if (!a || !w || !out || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
   if ((k & 7) || (n & 7) || lda != k || ldw != k || ldo < n || (ldo & 3)) return HCIR_ERR_INVALID;
   if ((epilogue == HCIR_EPI_AFFINE_RELU_F16 || epilogue == HCIR_EPI_AFFINE_F32) && !scale)
@@ -290,6 +291,7 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
 int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px, int32_t p,
                      const void* w_f16, const float* bias, const float* cls, const float* pos,
                      float pos_mult, int32_t d, float* tok, void* stream) {
+  HCIR_ENTER();
   if (!img || !w_f16 || !bias || !cls || !pos || !tok || b <= 0) return HCIR_ERR_INVALID;
   if (p != 16) return HCIR_ERR_UNSUPPORTED;  // ViT-*/16 only (ViT-L/14: DESIGN.md "next")
   if (c <= 0 || h % 16 || w_px % 16 || (d & 7)) return HCIR_ERR_INVALID;

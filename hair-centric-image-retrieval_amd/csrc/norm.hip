@@ -185,6 +185,7 @@ extern "C" {
 
 int hcir_layernorm_f16(const float* x, int64_t rows, int32_t d, int64_t ldx, const float* gamma,
                        const float* beta, float eps, void* y_f16, int64_t ldy, void* stream) {
+  HCIR_ENTER();
   if (!x || !gamma || !beta || !y_f16 || rows <= 0 || d <= 0 || (d & 3) || d > 2048)
     return HCIR_ERR_INVALID;
   if (ldx < d || ldy < d || (ldx & 3) || (ldy & 3)) return HCIR_ERR_INVALID;
@@ -202,6 +203,7 @@ int hcir_layernorm_f16(const float* x, int64_t rows, int32_t d, int64_t ldx, con
 int hcir_cls_head(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
                   const float* beta, float eps, int l2_normalize, float* emb_f32, void* emb_f16,
                   void* stream) {
+  HCIR_ENTER();
   if (!tok || b <= 0 || t <= 0 || d <= 0 || (d & 3) || d > 2048) return HCIR_ERR_INVALID;
   if ((gamma == nullptr) != (beta == nullptr)) return HCIR_ERR_INVALID;
   if (!emb_f32 && !emb_f16) return HCIR_ERR_INVALID;
@@ -218,6 +220,7 @@ int hcir_cls_head(const float* tok, int64_t b, int32_t t, int32_t d, const float
 
 int hcir_patch_mean(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
                     const float* beta, float eps, float* out_f32, void* stream) {
+  HCIR_ENTER();
   if (!tok || !out_f32 || b <= 0 || t <= 1 || d <= 0 || (d & 3) || d > 2048) return HCIR_ERR_INVALID;
   if ((gamma == nullptr) != (beta == nullptr)) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);

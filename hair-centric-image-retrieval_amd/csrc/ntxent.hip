@@ -1,0 +1,219 @@
+// ntxent.hip — fused NT-Xent forward: normalise -> 2B x 2B cosine / T -> masked row
+// log-sum-exp -> mean cross-entropy, without materialising the logits.
+//
+// Semantics: lightly.loss.NTXentLoss(temperature) as called at
+// HP/src/pretrain_engine.py:93,725 (== experiments/DualViewHair/src/losses/ntxent_loss.py:30-57):
+//   z = [normalize(z0); normalize(z1)], logits = z z^T / T, diagonal removed,
+//   positive of row i is (i + B) mod 2B, loss = mean_i(logsumexp_j logits[i][j] - logits[i][pos]).
+//
+// Kernels
+//   ntxent_prep   : one wave per row: x / max(||x||, 1e-12) (F.normalize eps) into the
+//                   workspace, in the compute dtype.
+//   ntxent_tiles  : sim_core.h tile engine; workgroup (x = column tile of 128, y = row block of
+//                   128); a lane owns one logits ROW and folds its 16 scores per MFMA tile
+//                   into an online (max, sum-of-exp2) pair; diagonal skipped, positive captured.
+//   ntxent_reduce : one workgroup: merges the per-(column tile, wave, half) partials of each
+//                   row in a fixed order (deterministic), writes row_lse and the mean loss.
+#include "sim_core.h"
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+template <typename T>
+__global__ __launch_bounds__(256) void ntxent_prep(const T* __restrict__ z0, const T* __restrict__ z1,
+                                                   int64_t b, int d, T* __restrict__ zn) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * b) return;
+  const T* p = row < b ? z0 + row * d : z1 + (row - b) * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float v = (float)p[k];
+    s = __builtin_fmaf(v, v, s);
+  }
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  for (int k = lane; k < d; k += 64) zn[row * d + k] = (T)((float)p[k] * inv);
+}
+
+struct NtArgs {
+  const void* zn;
+  float* pm;   // [nct][4][2B] running max (log2 domain)
+  float* pl;   // [nct][4][2B] sum of exp2
+  float* pp;   // [nct][4][2B] positive logit (log2 domain) or -inf
+  int64_t n;   // 2B
+  int64_t b;
+  int d;
+  float scale_log2;  // inv_t * log2(e)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ntxent_tiles(NtArgs a) {
+  using Cfg = SimCfg<T, 2, 2, 2>;  // 128 column rows streamed x 128 logits rows resident
+  constexpr int EPS = SimElem<T>::kPerStage;
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_c = wave >> 1, wave_r = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const T* zn = static_cast<const T*>(a.zn);
+  const int64_t c0 = (int64_t)blockIdx.x * 128, r0 = (int64_t)blockIdx.y * 128;
+  const int nkc = (a.d + EPS - 1) / EPS;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
+
+  u32x4 regs[Cfg::NLOAD];
+  sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, 0, tid);
+  sim_stage_store<Cfg>(regs, lds, tid);
+  __syncthreads();
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nkc) sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, kc + 1, tid);
+    sim_stage_mfma<T, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_c, wave_r, lane);
+    if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+    __syncthreads();
+  }
+
+  const float ninf = -__builtin_huge_valf();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int64_t row = r0 + wave_r * 64 + rt * 32 + r;
+    const int64_t pos = row < a.b ? row + a.b : row - a.b;
+    float m = ninf, l = 0.f, pv = ninf;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float x[16];
+      float tm = ninf;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t col = c0 + wave_c * 64 + ct * 32 + acc_row(i, h);
+        const float v = acc[ct][rt][i] * a.scale_log2;
+        const bool live = col < a.n && col != row;
+        x[i] = live ? v : ninf;
+        pv = (col == pos) ? v : pv;
+        tm = fmaxf(tm, x[i]);
+      }
+      if (tm > ninf) {
+        const float mn = fmaxf(m, tm);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(x[i] - mn);
+        l = l * __builtin_amdgcn_exp2f(m - mn) + sum;
+        m = mn;
+      }
+    }
+    if (row < a.n) {
+      const int src = wave_c * 2 + h;
+      const int64_t o = ((int64_t)blockIdx.x * 4 + src) * a.n + row;
+      a.pm[o] = m;
+      a.pl[o] = l;
+      a.pp[o] = pv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void ntxent_reduce(const float* __restrict__ pm,
+                                                      const float* __restrict__ pl,
+                                                      const float* __restrict__ pp, int64_t n,
+                                                      int nparts, float* __restrict__ loss,
+                                                      float* __restrict__ row_lse) {
+  __shared__ float red[1024];
+  float local = 0.f;
+  for (int64_t row = threadIdx.x; row < n; row += 1024) {
+    float m = -__builtin_huge_valf(), l = 0.f, pv = -__builtin_huge_valf();
+    for (int p = 0; p < nparts; ++p) {
+      const float mp = pm[(int64_t)p * n + row], lp = pl[(int64_t)p * n + row];
+      pv = fmaxf(pv, pp[(int64_t)p * n + row]);
+      if (lp > 0.f) {
+        const float mn = fmaxf(m, mp);
+        l = l * exp2f(m - mn) + lp * exp2f(mp - mn);
+        m = mn;
+      }
+    }
+    const float lse2 = m + log2f(l);  // log2 domain
+    if (row_lse) row_lse[row] = lse2 * kLn2;
+    local += (lse2 - pv) * kLn2;
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = red[0] / (float)n;
+}
+
+struct NtWorkspace {
+  void* zn;
+  float *pm, *pl, *pp;
+  size_t bytes;
+};
+
+NtWorkspace nt_carve(void* base, int64_t b, int d, int dtype) {
+  NtWorkspace w;
+  char* c = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    char* r = c ? c + off : nullptr;
+    off += (n + 255) & ~size_t(255);
+    return r;
+  };
+  const int64_t n = 2 * b;
+  const int64_t nct = hcir_cdiv(n, 128);
+  w.zn = take((size_t)n * d * (dtype == HCIR_F32 ? 4 : 2));
+  w.pm = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
+  w.pl = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
+  w.pp = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
+  w.bytes = off;
+  return w;
+}
+
+template <typename T>
+int nt_run(const void* z0, const void* z1, int64_t b, int d, float inv_t, float* loss, float* row_lse,
+           const NtWorkspace& w, hipStream_t st) {
+  const int64_t n = 2 * b;
+  const int nct = (int)hcir_cdiv(n, 128);
+  hipLaunchKernelGGL(ntxent_prep<T>, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0, st,
+                     static_cast<const T*>(z0), static_cast<const T*>(z1), b, d, static_cast<T*>(w.zn));
+  HCIR_LAUNCH_CHECK();
+  NtArgs a{w.zn, w.pm, w.pl, w.pp, n, b, d, inv_t * kLog2e};
+  hipLaunchKernelGGL(ntxent_tiles<T>, dim3(nct, nct), dim3(256), 0, st, a);
+  HCIR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ntxent_reduce, dim3(1), dim3(1024), 0, st, w.pm, w.pl, w.pp, n, nct * 4, loss,
+                     row_lse);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hcir_ntxent_workspace_bytes(int64_t b, int32_t d, int dtype) {
+  if (b <= 0 || d <= 0) return 0;
+  return nt_carve(nullptr, b, d, dtype).bytes;
+}
+
+int hcir_ntxent_fwd(const void* z0, const void* z1, int64_t b, int32_t d, int dtype, float inv_t,
+                    float* loss, float* row_lse, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  HCIR_ENTER();
+  if (!z0 || !z1 || !loss || b <= 0 || d <= 0 || (d & 7)) return HCIR_ERR_INVALID;
+  if (!(inv_t == inv_t) || inv_t == 0.f) return HCIR_ERR_INVALID;
+  if (dtype != HCIR_F32 && dtype != HCIR_F16 && dtype != HCIR_BF16) return HCIR_ERR_UNSUPPORTED;
+  const NtWorkspace w = nt_carve(workspace, b, d, dtype);
+  if (!workspace || workspace_bytes < w.bytes) return HCIR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HCIR_F32) return nt_run<float>(z0, z1, b, d, inv_t, loss, row_lse, w, st);
+  if (dtype == HCIR_F16) return nt_run<_Float16>(z0, z1, b, d, inv_t, loss, row_lse, w, st);
+  return nt_run<__bf16>(z0, z1, b, d, inv_t, loss, row_lse, w, st);
+}
+
+}  // extern "C"

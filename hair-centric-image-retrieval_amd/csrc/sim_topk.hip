@@ -544,6 +544,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
                   int dtype, const float* q_inv_norm, const float* g_inv_norm, int64_t idx_base,
                   float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
                   void* stream) {
+  HCIR_ENTER();
   if (!q || !g || !out_val || !out_idx) return HCIR_ERR_INVALID;
   if (nq <= 0 || ng <= 0 || d <= 0 || (d & 7) || k <= 0 || k > HCIR_TOPK_MAX) return HCIR_ERR_INVALID;
   if (k > ng || ng >= (int64_t(1) << 31)) return HCIR_ERR_INVALID;
@@ -656,6 +657,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
 
 int hcir_topk_merge(const float* vals, const int64_t* idx, int32_t nlists, int64_t nq, int32_t k_in,
                     int32_t k_out, float* out_val, int64_t* out_idx, void* stream) {
+  HCIR_ENTER();
   if (!vals || !idx || !out_val || !out_idx) return HCIR_ERR_INVALID;
   if (nlists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return HCIR_ERR_INVALID;
   if (nlists > 64 * kMergeLPL) return HCIR_ERR_UNSUPPORTED;
@@ -677,6 +679,7 @@ int hcir_topk_merge(const float* vals, const int64_t* idx, int32_t nlists, int64
 
 int hcir_row_invnorm(const void* x, int64_t n, int32_t d, int64_t ldx, int dtype, float eps,
                      float* out, void* stream) {
+  HCIR_ENTER();
   if (!x || !out || n <= 0 || d <= 0 || (d & 3) || ldx < d) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)hcir_cdiv(n, 4)), block(256);
@@ -694,6 +697,7 @@ int hcir_row_invnorm(const void* x, int64_t n, int32_t d, int64_t ldx, int dtype
 
 int hcir_l2_normalize(const float* x, int64_t n, int32_t d, float eps, float* y_f32, void* y_f16,
                       void* stream) {
+  HCIR_ENTER();
   if (!x || n <= 0 || d <= 0 || (d & 3)) return HCIR_ERR_INVALID;
   hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, n, d, eps, y_f32, (_Float16*)y_f16);
@@ -702,6 +706,7 @@ int hcir_l2_normalize(const float* x, int64_t n, int32_t d, float eps, float* y_
 }
 
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream) {
+  HCIR_ENTER();
   if (!x || !y || n <= 0) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int64_t blocks = hcir_cdiv(n, 1024);

@@ -10,6 +10,11 @@ import ctypes
 import os
 import subprocess
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It MUST be loaded before
+# libhcir.so so that the library's libamdhip64 dependency resolves to that same copy: two HIP
+# runtimes in one process cannot share streams or device pointers.
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
+
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libhcir.so")

@@ -1,0 +1,241 @@
+"""GPU parity of the remaining §8 rows: NT-Xent (a9), NegSamplerStatic (a10), models_vit (a5),
+MAE / SimCLR wrappers, ResNet-50 + top-5 (config C1 shape), Classifier.knn_eval (a6/a7),
+HairEncoder.retrieve_similar_images (a8)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import knn as oknn
+from oracle import ntxent as ont
+from oracle import transform as otf
+from oracle import vit as ovit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(hcir_built):
+    assert torch.cuda.is_available()
+
+
+def _cos_err(a, b):
+    return (1.0 - F.cosine_similarity(a.double(), b.double(), dim=-1)).abs().max().item()
+
+
+# ------------------------------------------------------------------ NT-Xent
+def test_ntxent_goldens_fp32(golden_dir):
+    """fp32 inputs (exact-fp32 MFMA): |loss - reference| <= 2e-5 (fp32 exp/log + summation order)."""
+    from hcir.losses import NTXentLoss
+    z = np.load(os.path.join(golden_dir, "ntxent_ref.npz"))
+    for i in range(int(z["n"])):
+        z0, z1 = torch.from_numpy(z[f"z0_{i}"]).cuda(), torch.from_numpy(z[f"z1_{i}"]).cuda()
+        with torch.no_grad():
+            loss = NTXentLoss(temperature=float(z[f"t_{i}"]))(z0, z1)
+        assert loss.dim() == 0 and loss.is_cuda
+        assert abs(loss.item() - float(z[f"loss_{i}"])) <= 2e-5 * max(1.0, abs(float(z[f"loss_{i}"])))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("b,d,t", [(1024, 512, 0.5), (256, 1024, 0.7), (37, 72, 0.07)])
+def test_ntxent_config_c3(dtype, tol, b, d, t):
+    """BASELINE config C3: B=1024, D=512.  fp16/bf16 inputs as under the reference's autocast;
+    tolerance = input rounding of the normalised rows times 1/T, relative to the fp64 oracle."""
+    from hcir.losses import ntxent_forward
+    g = torch.Generator().manual_seed(b + d)
+    z0, z1 = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g)
+    z0d, z1d = z0.cuda().to(dtype), z1.cuda().to(dtype)
+    loss, lse = ntxent_forward(z0d, z1d, t, want_lse=True)
+    ref, ref_lse = ont.ntxent_f64(z0d.float().cpu(), z1d.float().cpu(), t)
+    assert abs(loss.item() - ref.item()) <= tol * max(1.0, abs(ref.item())) / min(1.0, t * 2)
+    np.testing.assert_allclose(lse.cpu().numpy(), ref_lse.numpy(), atol=tol * 10 / min(1.0, t * 2), rtol=0)
+
+
+def test_ntxent_errors():
+    from hcir.losses import NTXentLoss
+    z = torch.randn(8, 16, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        NTXentLoss(0.5)(z, z)
+    with pytest.raises(ValueError):
+        NTXentLoss(1e-9)
+
+
+# ------------------------------------------------------------------ backbones
+def _randomize(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+            if not p.dtype.is_floating_point:
+                continue
+            if "running_var" in name:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif "norm" in name and name.endswith("weight") or name.endswith(("ln_1.weight", "ln_2.weight", "ln.weight")):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif "gamma" in name:
+                p.copy_(0.5 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.dim() <= 1 or "cls_token" in name or "pos_emb" in name:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+
+
+def test_models_vit_forward_features_vs_oracle():
+    from hcir.models_vit import vit_base_patch16
+    torch.manual_seed(3)
+    m = vit_base_patch16(drop_path_rate=0.1, global_pool=True, init_values=None).eval()
+    _randomize(m, 4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    ref = ovit.models_vit_forward_features(sd, x)
+    m = m.cuda()
+    with torch.no_grad():
+        out = m.forward_features(x.cuda()).cpu()
+    assert out.shape == (3, 197, 768)
+    assert _cos_err(out[:, 0], ref[:, 0]) <= 1e-3          # what HairEncoder consumes
+    assert _cos_err(out.reshape(3 * 197, 768), ref.reshape(3 * 197, 768)) <= 1e-3
+
+
+def test_models_vit_layerscale():
+    from hcir.models_vit import vit_base_patch16
+    torch.manual_seed(6)
+    m = vit_base_patch16(drop_path_rate=0.0, global_pool=True, init_values=0.1).eval()
+    _randomize(m, 7)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    ref = ovit.models_vit_forward_features(sd, x)
+    with torch.no_grad():
+        out = m.cuda().forward_features(x.cuda()).cpu()
+    assert _cos_err(out[:, 0], ref[:, 0]) <= 1e-3
+
+
+def test_mae_extract_features():
+    from hcir.backbone import MAE, vit_base_patch16_224
+    torch.manual_seed(9)
+    m = MAE(vit_base_patch16_224()).eval()
+    _randomize(m, 10)
+    sd = {k[len("backbone.vit."):]: v.clone() for k, v in m.state_dict().items() if k.startswith("backbone.vit.")}
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    tok = ovit.models_vit_forward_features(sd, x)
+    ref = F.layer_norm(tok, (768,), sd["norm.weight"], sd["norm.bias"], 1e-6)[:, 0]
+    with torch.no_grad():
+        out = m.cuda().extract_features(x.cuda()).cpu()
+    assert _cos_err(out, ref) <= 1e-3
+
+
+def test_config_c1_resnet50_top5(golden_dir):
+    """BASELINE config C1 shape: ResNet-50 embed of 64 crops cut from the sample assets, top-5 over a
+    1000 x 2048 gallery.  ResNet runs on PyTorch-ROCm (MIOpen); the scan is hcir_sim_topk.
+    Embedding tolerance 1e-3 cosine; top-5 of the GPU embeddings bit-exact vs the oracle scan."""
+    from hcir import ops
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(42)
+    m = SHAM2("resnet50").eval()
+    _randomize(m, 12)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    win = np.load(os.path.join(golden_dir, "asset_windows.npz"))["windows"]
+    rng = np.random.default_rng(0)
+    crops = [otf.window_to_tensor(w) for w in win]
+    while len(crops) < 64:   # further deterministic 224^2 windows: shifted/flipped views of the asset windows
+        w = win[len(crops) % 4]
+        dy, dx = rng.integers(0, 32, 2)
+        crops.append(otf.window_to_tensor(np.roll(w, (dy, dx), (0, 1))[:, ::(-1) ** len(crops)]))
+    x = torch.from_numpy(np.stack(crops))
+    ref = ovit.classifier_embed(sd, x, "resnet50")
+    g = F.normalize(torch.randn(1000, 2048, generator=torch.Generator().manual_seed(0)), dim=1)
+    with torch.no_grad():
+        emb = ops.l2_normalize(m.cuda().extract_features(x.cuda()).contiguous())
+        val, idx = ops.sim_topk(emb, g.cuda(), 5)
+    assert _cos_err(emb.cpu(), ref) <= 1e-3
+    rv, ri = oknn.cosine_topk(emb.cpu().numpy(), g.numpy(), 5)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)
+
+
+# ------------------------------------------------------------------ engines
+class _FixedFeatureModel(torch.nn.Module):
+    """Duck-typed model (extract_features) returning rows of a fixed table keyed by the first pixel."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.table = torch.nn.Parameter(table, requires_grad=False)
+
+    def extract_features(self, x):
+        return self.table[x[:, 0, 0, 0].long()]
+
+
+def test_classifier_knn_eval_vs_sklearn(tmp_path):
+    from sklearn.neighbors import KNeighborsClassifier
+    from hcir.classification_engine import Classifier
+    rng = np.random.default_rng(1)
+    ntr, nte, d, ncls = 900, 120, 96, 6
+    centers = rng.standard_normal((ncls, d)).astype(np.float32) * 1.5
+    ytr, yte = rng.integers(0, ncls, ntr), rng.integers(0, ncls, nte)
+    ftr = centers[ytr] + rng.standard_normal((ntr, d)).astype(np.float32)
+    fte = centers[yte] + rng.standard_normal((nte, d)).astype(np.float32)
+    table = torch.from_numpy(np.concatenate([ftr, fte]))
+
+    def loader(lo, n, ys):
+        out = []
+        for s in range(0, n, 64):
+            e = min(n, s + 64)
+            img = torch.zeros(e - s, 3, 2, 2)
+            img[:, 0, 0, 0] = torch.arange(lo + s, lo + e).float()
+            out.append((img, torch.from_numpy(ys[s:e])))
+        return out
+
+    args = types.SimpleNamespace(device="cuda", mode="SHAM", model="vit_b_16", SHAM_mode="embedding",
+                                 save_path=str(tmp_path))
+    clf = Classifier(_FixedFeatureModel(table), loader(0, ntr, ytr), loader(ntr, nte, yte), args)
+    ks = (5, 10, 27, 642)
+    clf.knn_eval(ks=ks)
+    txt = open(tmp_path / "SHAM_vit_b_16_embedding" / "knn_evaluation_results.txt").read()
+    gtr = F.normalize(torch.from_numpy(ftr), dim=1)
+    gte = F.normalize(torch.from_numpy(fte), dim=1)
+    for k in ks:
+        knn = KNeighborsClassifier(n_neighbors=k, metric="cosine").fit(gtr, torch.from_numpy(ytr))
+        acc = float((knn.predict(gte) == yte).mean())
+        assert f"Results for k={k}\n" in txt
+        assert f"Accuracy: {acc:.4f}" in txt.split(f"Results for k={k}\n")[1].split("=" * 50)[0]
+    dist, idx = clf.kneighbors(10)
+    sd, si = KNeighborsClassifier(n_neighbors=10, metric="cosine").fit(gtr, ytr).kneighbors(gte)
+    np.testing.assert_array_equal(idx.cpu().numpy(), si)
+    np.testing.assert_allclose(dist.cpu().numpy(), sd, atol=1e-6, rtol=0)
+    with pytest.raises(ValueError):     # k > n_samples_fit: sklearn's error, mirrored
+        clf.knn_eval(ks=(901,))
+
+
+def test_neg_sampler_static():
+    from hcir.neg_sampling import NegSamplerStatic
+    rng = np.random.default_rng(2)
+    emb = torch.from_numpy(rng.standard_normal((256, 768)).astype(np.float32) * 2)
+    model = types.SimpleNamespace(extract_features_ema=lambda batch: emb.cuda()[batch.long()])
+    batch = torch.arange(256).cuda()
+    for k in (1, 7, 15):
+        got = NegSamplerStatic(model, batch, metric="cosine", k=k).cpu().numpy()
+        np.testing.assert_array_equal(got, oknn.neg_sampler_static_np(emb.numpy(), k))
+    assert (NegSamplerStatic(model, batch, k=1).cpu().numpy() == np.arange(256)).all()  # self is rank 0
+    with pytest.raises(ValueError):
+        NegSamplerStatic(model, batch, k=257)
+    with pytest.raises(ValueError):
+        NegSamplerStatic(model, batch, metric="manhattan", k=3)
+
+
+def test_hair_encoder_retrieve(golden_dir, tmp_path):
+    from hcir.hair_encoder import HairEncoder
+    z = np.load(os.path.join(golden_dir, "knn_sklearn.npz"))
+    enc = HairEncoder(None, "vit_base_patch16", device="cuda")
+    for i in range(int(z["n"])):
+        g = z[f"g_{i}"] * z[f"ret_gscale_{i}"]
+        paths = [f"img_{j}.png" for j in range(len(g))]
+        res = enc.retrieve_similar_images(z[f"ret_q_{i}"], g, paths, top_k=int(z[f"k_{i}"]))
+        assert [r["path"] for r in res] == [paths[j] for j in z[f"ret_idx_{i}"]]
+        np.testing.assert_allclose([r["similarity"] for r in res], z[f"ret_sim_{i}"], atol=1e-6, rtol=0)
+    enc.save_embeddings(g, paths, str(tmp_path))
+    assert enc.check_embeddings_exist(str(tmp_path))
+    g2, p2 = enc.load_embeddings(str(tmp_path))
+    assert np.array_equal(g2, g) and p2 == paths
+    x = torch.randn(2, 3, 224, 224)
+    feats = enc.extract_features(x.cuda())
+    ref = ovit.models_vit_forward_features({k: v.cpu() for k, v in enc.model.state_dict().items()}, x)[:, 0]
+    assert _cos_err(feats.cpu(), ref) <= 1e-3

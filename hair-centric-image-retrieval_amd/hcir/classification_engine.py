@@ -69,6 +69,9 @@ class Classifier:
 
     def extracting_features(self):
         self.model.eval()
+        # (re)start from empty lists so that a second evaluation on the same object works
+        self.training_features, self.training_labels = [], []
+        self.testing_features, self.testing_labels = [], []
         with torch.no_grad():
             self._embed(self.train_loader, self.training_features, self.training_labels)
             self._embed(self.test_loader, self.testing_features, self.testing_labels)

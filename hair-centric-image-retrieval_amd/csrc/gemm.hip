@@ -39,19 +39,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2],
-                                              int64_t m0, int n0, int wave_n, int wave_m, int lane) {
+template <int EPI, int NTILES>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 (&acc)[NTILES][2],
+                                                int64_t m0, int nbase, int wave_m, int lane) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int64_t m = m0 + wave_m * 64 + mt * 32 + r;
     if (m >= g.m) continue;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTILES; ++nt) {
 #pragma unroll
       for (int grp = 0; grp < 4; ++grp) {
-        const int n = n0 + wave_n * 64 + nt * 32 + 8 * grp + 4 * h;
+        const int n = nbase + nt * 32 + 8 * grp + 4 * h;
         if (n >= g.n) continue;
         f32x4 v;
 #pragma unroll
@@ -98,7 +98,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_n, int tiles_m) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2],
+                                              int64_t m0, int n0, int wave_n, int wave_m, int lane) {
+  gemm_epilogue_t<EPI, 2>(g, acc, m0, n0 + wave_n * 64, wave_m, lane);
+}
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue256(const GemmArgs& g, const f32x16 (&acc)[4][2],
+                                                 int64_t m0, int nbase, int wave_m, int lane) {
+  gemm_epilogue_t<EPI, 4>(g, acc, m0, nbase, wave_m, lane);
+}
+
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_n, int tiles_m) {
   using Cfg = GemmCfg;
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,19 +132,192 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g, int tiles_n, 
 
   // The tile engine addresses rows as base + row * d: lda == ldw == k is required
   // (checked on the host); "d" is the row length in elements.
-  u32x4 regs[Cfg::NLOAD];
-  sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, 0, tid);
-  sim_stage_store<Cfg>(regs, lds, tid);
-  __syncthreads();
-  for (int kc = 0; kc < nkc; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nkc)
-      sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, kc + 1, tid);
-    sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
-    if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+  if constexpr (GLDS) {
+    // K % 64 == 0: LDS-DMA straight into the double buffer, next stage issued before the MFMAs
+    // of the current one; __syncthreads() waits for the DMA (vmcnt) and the barrier.
+    sim_stage_glds<_Float16, Cfg>(lds, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, 0, tid);
     __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nkc)
+        sim_stage_glds<_Float16, Cfg>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g.w, n0, g.n - 1, g.a, m0,
+                                      g.m - 1, g.k, kc + 1, tid);
+      sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
+      __syncthreads();
+    }
+  } else {
+    // ragged K: register-staged, zero-filled past K
+    u32x4 regs[Cfg::NLOAD];
+    sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, 0, tid);
+    sim_stage_store<Cfg>(regs, lds, tid);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nkc)
+        sim_stage_load<_Float16, Cfg>(regs, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, kc + 1, tid);
+      sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
+      if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+      __syncthreads();
+    }
   }
   gemm_epilogue<EPI>(g, acc, m0, n0, wave_n, wave_m, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Big-tile GEMM: 256(n) x 256(m) per workgroup, 8 waves as 2(n) x 4(m), each wave
+// 128(n) x 64(m) = 4 x 2 MFMA 32x32x16 tiles (128 accumulator registers), persistent
+// over tiles.  Why this geometry (measured, DESIGN.md "GEMM ablation"): with 64 x 64
+// wave tiles the LDS pipe (fragment reads + DMA writes, ~170 B/clk of 256) is the limit,
+// DMA and MFMA phases add instead of overlapping, and compute alone tops out at 1.24 PF.
+// 128 x 64 wave tiles cut LDS reads per MFMA by 25 % and L2->LDS traffic per flop by 2x.
+//
+// K is staged in 32-wide chunks: a stage is 512 rows x 64 B = 32 KB; FOUR slots form a
+// ring filled by LDS-DMA, THREE stages in flight across the single raw barrier of a k-step
+// (counted vmcnt, never 0 in the loop):
+//   step s:  s_waitcnt vmcnt(2*NLOAD) -> this wave's DMA of stage s landed (s+1, s+2 still fly)
+//            s_barrier                -> everyone's stage s landed; slot (s+3)%4 is free
+//            per k-substep: fragment ds_reads, then the DMA pieces of stage s+3, then MFMAs
+// 64-B rows: 16-B slots swizzled with (row>>2)&3 (4 rows share a 256-B bank row), applied
+// on the DMA source address and on the fragment read.  Requires K % 32 == 0.
+// ---------------------------------------------------------------------------
+struct G256 {
+  static constexpr int NT = 512;
+  static constexpr int ROWS = 512;              // 256 W rows (n) then 256 activation rows (m)
+  static constexpr int STAGE_BYTES = ROWS * 64; // 32 KB
+  static constexpr int NSLOT = 4;
+  static constexpr int NLOAD = ROWS * 4 / NT;   // 16-B pieces per thread per stage = 4
+};
+
+__device__ __forceinline__ int g256_off(int row, int chunk) {
+  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int tiles_n, int tiles_m) {
+  __shared__ __attribute__((aligned(16))) char lds[G256::NSLOT * G256::STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 2, wave_m = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int ntiles = tiles_n * tiles_m;
+  const int nkc = g.k / 32;
+  const int my_tiles =
+      (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nsteps = my_tiles * nkc;
+
+  auto tile_origin = [&](int ti, int& n0, int64_t& m0) {
+    const int t = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
+    n0 = (t % tiles_n) * 256;
+    m0 = (int64_t)(t / tiles_n) * 256;
+  };
+
+  // per-thread DMA source pointers of the current "issue" tile (row base + swizzled chunk)
+  const _Float16* src[G256::NLOAD];
+  auto set_sources = [&](int ti) {
+    int n0;
+    int64_t m0;
+    tile_origin(ti, n0, m0);
+#pragma unroll
+    for (int i = 0; i < G256::NLOAD; ++i) {
+      const int piece = tid + G256::NT * i;
+      const int row = piece >> 2, chunk = (piece & 3) ^ ((row >> 2) & 3);
+      if (row < 256) {
+        int nr = n0 + row;
+        nr = nr > g.n - 1 ? g.n - 1 : nr;
+        src[i] = g.w + (int64_t)nr * g.k + chunk * 8;
+      } else {
+        int64_t mr = m0 + (row - 256);
+        mr = mr > g.m - 1 ? g.m - 1 : mr;
+        src[i] = g.a + mr * (int64_t)g.k + chunk * 8;
+      }
+    }
+  };
+  int issue_ti = 0, issue_kc = 0;  // next stage to issue
+  auto issue_piece = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src[i] + issue_kc * 32),
+        (__attribute__((address_space(3))) void*)(lds + slot * G256::STAGE_BYTES +
+                                                   ((tid & ~63) + G256::NT * i) * 16),
+        16, 0, 0);
+  };
+  auto issue_advance = [&]() {
+    if (++issue_kc == nkc) {
+      issue_kc = 0;
+      ++issue_ti;
+      if (issue_ti < my_tiles) set_sources(issue_ti);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  if (my_tiles > 0) set_sources(0);
+  // prologue: stages 0, 1, 2
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    if (p < nsteps) {
+#pragma unroll
+      for (int i = 0; i < G256::NLOAD; ++i) issue_piece(p, i);
+      issue_advance();
+    }
+  }
+
+  int kc = 0, ti = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const int remaining = nsteps - 1 - step;  // stages issued after `step` that may still fly
+    if (remaining >= 2)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G256::NLOAD) : "memory");
+    else if (remaining == 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G256::NLOAD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const char* st = lds + (step & 3) * G256::STAGE_BYTES;
+    const bool do_issue = step + 3 < nsteps;
+    const int islot = (step + 3) & 3;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = 2 * ks + h;
+      u32x4 af[4], bf[2];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        af[nt] = *reinterpret_cast<const u32x4*>(st + g256_off(wave_n * 128 + nt * 32 + r, chunk));
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        bf[mt] = *reinterpret_cast<const u32x4*>(st + g256_off(256 + wave_m * 64 + mt * 32 + r, chunk));
+      if (do_issue) {  // two of the four DMA pieces of stage step+3 per k-substep
+        issue_piece(islot, 2 * ks);
+        issue_piece(islot, 2 * ks + 1);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+              __builtin_bit_cast(f16x8, af[nt]), __builtin_bit_cast(f16x8, bf[mt]), acc[nt][mt], 0, 0, 0);
+    }
+    if (do_issue) issue_advance();
+
+    if (++kc == nkc) {
+      int n0;
+      int64_t m0;
+      tile_origin(ti, n0, m0);
+      gemm_epilogue256<EPI>(g, acc, m0, n0 + wave_n * 128, wave_m, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+      kc = 0;
+      ++ti;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -254,9 +438,19 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
 
 template <int EPI>
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
+  if (g.k % 32 == 0 && g.m >= 1024 && g.n >= 256) {
+    const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
+    const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
+    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+    return;
+  }
   const int tiles_n = (int)hcir_cdiv(g.n, 128), tiles_m = (int)hcir_cdiv(g.m, 128);
-  hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3(tiles_n * tiles_m), dim3(256), 0, st, g, tiles_n,
-                     tiles_m);
+  if (g.k % 64 == 0)
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles_n * tiles_m), dim3(256), 0, st, g,
+                       tiles_n, tiles_m);
+  else
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, false>), dim3(tiles_n * tiles_m), dim3(256), 0, st, g,
+                       tiles_n, tiles_m);
 }
 
 }  // namespace

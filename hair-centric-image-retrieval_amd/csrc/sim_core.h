@@ -45,6 +45,7 @@ struct SimElem<__bf16> {
 template <typename T, int WGG, int WQ, int QT>
 struct SimCfg {
   static_assert(WGG * WQ == 4, "4 waves per workgroup");
+  static constexpr int NT = 256;             // threads per workgroup
   static constexpr int GM = 64 * WGG;        // stream rows per WG tile
   static constexpr int QB = 32 * QT * WQ;    // resident rows per WG
   static constexpr int ROWS = GM + QB;       // rows staged per chunk
@@ -52,6 +53,17 @@ struct SimCfg {
   static constexpr int STAGE_BYTES = ROWS * 128;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
   static_assert((ROWS * 8) % 256 == 0, "slot count must divide evenly");
+};
+
+// 8-wave configuration for the big GEMM tile: 2 x 4 waves, each 2x2 MFMA tiles:
+// 128 stream rows (W) x 256 resident rows (activations), 48 KB per stage.
+struct SimCfgBig {
+  static constexpr int NT = 512;
+  static constexpr int GM = 128;
+  static constexpr int QB = 256;
+  static constexpr int ROWS = GM + QB;
+  static constexpr int NLOAD = ROWS * 8 / NT;  // 6
+  static constexpr int STAGE_BYTES = ROWS * 128;
 };
 
 __device__ __forceinline__ int sim_slot_off(int row, int chunk) {
@@ -97,6 +109,43 @@ __device__ __forceinline__ void sim_stage_store(const u32x4 (&regs)[Cfg::NLOAD],
     const int slot = tid + 256 * i;
     const int row = slot >> 3, chunk = slot & 7;
     *reinterpret_cast<u32x4*>(stage + sim_slot_off(row, chunk)) = regs[i];
+  }
+}
+
+// LDS-DMA staging (global_load_lds_dwordx4): one wave instruction writes 64 consecutive
+// 16-B slots = 8 rows x 128 B of the stage image; the LDS destination is wave-uniform
+// base + lane*16, so the XOR swizzle is applied to the per-lane SOURCE address (the lane
+// that fills physical slot p of row r fetches logical chunk p ^ ((r>>1)&7)); the 8 lanes of a
+// row still cover one whole 128-B line (cdna_hip_programming.md §5 caveat, rule 21).
+// No VGPR round trip and no ds_write: the register-staged path is bound by the
+// ds_write_b128 VGPR->LDS transfer (~79 B/clk/CU).  Requires d % (elements per stage) == 0.
+template <typename T, typename Cfg>
+__device__ __forceinline__ void sim_stage_glds(char* stage, const T* __restrict__ g, int64_t g_row0,
+                                               int64_t g_last, const T* __restrict__ q,
+                                               int64_t q_row0, int64_t q_last, int d, int kc,
+                                               int tid) {
+  constexpr int EPC = SimElem<T>::kPerChunk;
+  constexpr int EPS = SimElem<T>::kPerStage;
+  const int wave_base = tid & ~63;
+#pragma unroll
+  for (int i = 0; i < Cfg::NLOAD; ++i) {
+    const int slot = tid + Cfg::NT * i;
+    const int row = slot >> 3, pslot = slot & 7;
+    const int chunk = pslot ^ ((row >> 1) & 7);
+    const int k0 = kc * EPS + chunk * EPC;
+    const T* src;
+    if (row < Cfg::GM) {
+      int64_t gr = g_row0 + row;
+      gr = gr > g_last ? g_last : gr;
+      src = g + gr * (int64_t)d + k0;
+    } else {
+      int64_t qr = q_row0 + (row - Cfg::GM);
+      qr = qr > q_last ? q_last : qr;
+      src = q + qr * (int64_t)d + k0;
+    }
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)src,
+        (__attribute__((address_space(3))) void*)(stage + (wave_base + Cfg::NT * i) * 16), 16, 0, 0);
   }
 }
 

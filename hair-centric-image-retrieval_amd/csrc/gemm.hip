@@ -17,8 +17,20 @@ namespace {
 
 using GemmCfg = SimCfg<_Float16, 2, 2, 2>;  // GM = 128 W rows, QB = 128 A rows
 
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// far below the fp16 rounding of the output): 1 rcp + 1 exp2 + 7 fma instead of erff's ~40
+// instructions — the fc1 epilogue evaluates it 16K times per wave tile.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = __builtin_fmaf(-p * t, e, 1.0f);
+  const float erfv = __builtin_copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erfv);
 }
 
 struct GemmArgs {
@@ -108,6 +120,113 @@ __device__ __forceinline__ void gemm_epilogue256(const GemmArgs& g, const f32x16
   gemm_epilogue_t<EPI, 4>(g, acc, m0, nbase, wave_m, lane);
 }
 
+// Epilogue of the 256 x 256 kernel: every wave transposes its 128(n) x 64(m) accumulator tile
+// through a private 8 KB piece of the LDS slot that the tile's last k-step has just released,
+// 64 B of n per row at a time, so that a lane ends up with 16 contiguous bytes of ONE output
+// row and 8 lanes cover a whole 128-B line (the direct layout gives every lane 8 B of a different
+// row: 1.6-1.9 TB/s effective on the fp16 outputs).  Bias / GELU / residual run on the
+// row-contiguous side.  [64 rows][128 B] image, 16-B chunks XOR-swizzled with row & 7.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f32x16 (&acc)[4][2],
+                                                     char* region, int64_t m0w, int nbase, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 ||
+                         EPI == HCIR_EPI_AFFINE_RELU_F16);
+  constexpr int NPASS = kF16 ? 2 : 4;     // 64 or 32 output features (128 B) per pass
+  const int rrow = lane >> 3, rchunk = lane & 7;
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // ---- accumulators -> LDS (lane = output row m, registers = features n)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 32 + r;
+      if constexpr (kF16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int nt = 2 * pass + q;
+#pragma unroll
+          for (int grp = 0; grp < 4; ++grp) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[nt][mt][4 * grp + e];
+            const int chunk = q * 4 + grp;
+            *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[pass][mt][4 * grp + e];
+          const int chunk = 2 * grp + h;
+          *reinterpret_cast<f32x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4)) = o;
+        }
+      }
+    }
+    // ---- LDS -> rows: lane = (row rrow + 8 it, 16-B chunk rchunk)
+    if constexpr (kF16) {
+      const int n = nbase + pass * 64 + rchunk * 8;
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, s0 = b0, s1 = b0;
+      if (g.bias) {
+        b0 = *reinterpret_cast<const f32x4*>(g.bias + n);
+        b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+      }
+      if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+        s0 = *reinterpret_cast<const f32x4*>(g.scale + n);
+        s1 = *reinterpret_cast<const f32x4*>(g.scale + n + 4);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + rrow;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = (float)v[e];
+          const float bb = e < 4 ? b0[e & 3] : b1[e & 3];
+          if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+            x = fmaxf(__builtin_fmaf(x, e < 4 ? s0[e & 3] : s1[e & 3], bb), 0.f);
+          } else {
+            x += bb;
+            if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
+          }
+          o[e] = (_Float16)x;
+        }
+        const int64_t m = m0w + row;
+        if (m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+      }
+    } else {
+      const int n = nbase + pass * 32 + rchunk * 4;
+      f32x4 b = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f};
+      if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if (g.scale) sc = *reinterpret_cast<const f32x4*>(g.scale + n);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + rrow;
+        const int64_t mm = m0w + row;
+        f32x4 oldv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+          if (mm < g.m) oldv = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+        if constexpr (EPI == HCIR_EPI_AFFINE_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], b[e]);
+        } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(sc[e], v[e] + b[e], oldv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        const int64_t m = m0w + row;
+        if (m < g.m) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + m * g.ldo + n) = v;
+      }
+    }
+  }
+}
+
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_n, int tiles_m) {
   using Cfg = GemmCfg;
@@ -167,39 +286,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 // Big-tile GEMM: 256(n) x 256(m) per workgroup, 8 waves as 2(n) x 4(m), each wave
 // 128(n) x 64(m) = 4 x 2 MFMA 32x32x16 tiles (128 accumulator registers), persistent
 // over tiles.  Why this geometry (measured, DESIGN.md "GEMM ablation"): with 64 x 64
-// wave tiles the LDS pipe (fragment reads + DMA writes, ~170 B/clk of 256) is the limit,
-// DMA and MFMA phases add instead of overlapping, and compute alone tops out at 1.24 PF.
-// 128 x 64 wave tiles cut LDS reads per MFMA by 25 % and L2->LDS traffic per flop by 2x.
+// wave tiles the LDS pipe (fragment reads + DMA writes, ~170 B/clk of 256) is the limit
+// and compute alone tops out at 1.24 PF; 128 x 64 wave tiles cut LDS reads per MFMA by
+// 25 % and L2->LDS traffic per flop by 2x.  Rows stay 128 B (BK = 64): with 64-B row
+// pieces (BK = 32) the LDS-DMA path moved 2.2-2.8x fewer bytes per second.
 //
-// K is staged in 32-wide chunks: a stage is 512 rows x 64 B = 32 KB; FOUR slots form a
-// ring filled by LDS-DMA, THREE stages in flight across the single raw barrier of a k-step
-// (counted vmcnt, never 0 in the loop):
-//   step s:  s_waitcnt vmcnt(2*NLOAD) -> this wave's DMA of stage s landed (s+1, s+2 still fly)
-//            s_barrier                -> everyone's stage s landed; slot (s+3)%4 is free
-//            per k-substep: fragment ds_reads, then the DMA pieces of stage s+3, then MFMAs
-// 64-B rows: 16-B slots swizzled with (row>>2)&3 (4 rows share a 256-B bank row), applied
-// on the DMA source address and on the fragment read.  Requires K % 32 == 0.
+// A stage is 512 rows x 128 B = 64 KB; two slots.  Step s: wait for stage s (vmcnt(0)),
+// barrier, then the eight DMA pieces of stage s+1 are issued between the fragment reads
+// and the MFMAs of the FIRST two k-substeps, so that they have the rest of the step (24+
+// MFMAs per wave) to land.  Stages run on across tile boundaries: the next tile's first
+// stage flies under the epilogue.  Requires K % 64 == 0.
 // ---------------------------------------------------------------------------
 struct G256 {
   static constexpr int NT = 512;
-  static constexpr int ROWS = 512;              // 256 W rows (n) then 256 activation rows (m)
-  static constexpr int STAGE_BYTES = ROWS * 64; // 32 KB
-  static constexpr int NSLOT = 4;
-  static constexpr int NLOAD = ROWS * 4 / NT;   // 16-B pieces per thread per stage = 4
+  static constexpr int ROWS = 512;               // 256 W rows (n) then 256 activation rows (m)
+  static constexpr int STAGE_BYTES = ROWS * 128; // 64 KB
+  static constexpr int NLOAD = ROWS * 8 / NT;    // 16-B pieces per thread per stage = 8
 };
-
-__device__ __forceinline__ int g256_off(int row, int chunk) {
-  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int tiles_n, int tiles_m) {
-  __shared__ __attribute__((aligned(16))) char lds[G256::NSLOT * G256::STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[2 * G256::STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_n = wave >> 2, wave_m = wave & 3;
   const int r = lane & 31, h = lane >> 5;
   const int ntiles = tiles_n * tiles_m;
-  const int nkc = g.k / 32;
+  const int nkc = g.k / 64;
   const int my_tiles =
       (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int nsteps = my_tiles * nkc;
@@ -210,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     m0 = (int64_t)(t / tiles_n) * 256;
   };
 
-  // per-thread DMA source pointers of the current "issue" tile (row base + swizzled chunk)
+  // per-thread DMA source pointers of the tile being issued (row base + swizzled chunk)
   const _Float16* src[G256::NLOAD];
   auto set_sources = [&](int ti) {
     int n0;
@@ -219,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
 #pragma unroll
     for (int i = 0; i < G256::NLOAD; ++i) {
       const int piece = tid + G256::NT * i;
-      const int row = piece >> 2, chunk = (piece & 3) ^ ((row >> 2) & 3);
+      const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
       if (row < 256) {
         int nr = n0 + row;
         nr = nr > g.n - 1 ? g.n - 1 : nr;
@@ -234,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
   int issue_ti = 0, issue_kc = 0;  // next stage to issue
   auto issue_piece = [&](int slot, int i) {
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src[i] + issue_kc * 32),
+        (const __attribute__((address_space(1))) void*)(src[i] + issue_kc * 64),
         (__attribute__((address_space(3))) void*)(lds + slot * G256::STAGE_BYTES +
                                                    ((tid & ~63) + G256::NT * i) * 16),
         16, 0, 0);
@@ -255,44 +367,34 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  if (my_tiles > 0) set_sources(0);
-  // prologue: stages 0, 1, 2
+  if (nsteps > 0) {
+    set_sources(0);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    if (p < nsteps) {
-#pragma unroll
-      for (int i = 0; i < G256::NLOAD; ++i) issue_piece(p, i);
-      issue_advance();
-    }
+    for (int i = 0; i < G256::NLOAD; ++i) issue_piece(0, i);
+    issue_advance();
   }
 
   int kc = 0, ti = 0;
   for (int step = 0; step < nsteps; ++step) {
-    const int remaining = nsteps - 1 - step;  // stages issued after `step` that may still fly
-    if (remaining >= 2)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G256::NLOAD) : "memory");
-    else if (remaining == 1)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G256::NLOAD) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const char* st = lds + (step & 3) * G256::STAGE_BYTES;
-    const bool do_issue = step + 3 < nsteps;
-    const int islot = (step + 3) & 3;
+    const char* st = lds + (step & 1) * G256::STAGE_BYTES;
+    const bool do_issue = step + 1 < nsteps;
+    const int islot = (step + 1) & 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       const int chunk = 2 * ks + h;
       u32x4 af[4], bf[2];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
-        af[nt] = *reinterpret_cast<const u32x4*>(st + g256_off(wave_n * 128 + nt * 32 + r, chunk));
+        af[nt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_n * 128 + nt * 32 + r, chunk));
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        bf[mt] = *reinterpret_cast<const u32x4*>(st + g256_off(256 + wave_m * 64 + mt * 32 + r, chunk));
-      if (do_issue) {  // two of the four DMA pieces of stage step+3 per k-substep
-        issue_piece(islot, 2 * ks);
-        issue_piece(islot, 2 * ks + 1);
+        bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_m * 64 + mt * 32 + r, chunk));
+      if (do_issue && ks < 2) {  // four of the eight DMA pieces of stage step+1 per early k-substep
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * ks + i);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -307,7 +409,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       int n0;
       int64_t m0;
       tile_origin(ti, n0, m0);
-      gemm_epilogue256<EPI>(g, acc, m0, n0 + wave_n * 128, wave_m, lane);
+      // all waves are done reading slot step&1 (their MFMAs have consumed it) after this barrier;
+      // the slot stays free until the DMA of stage step+2 is issued behind the next step's barrier
+      __builtin_amdgcn_s_barrier();
+      gemm_epilogue256_lds<EPI>(g, acc, lds + (step & 1) * G256::STAGE_BYTES + wave * 8192,
+                                m0 + wave_m * 64, n0 + wave_n * 128, lane);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -438,7 +544,7 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
 
 template <int EPI>
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  if (g.k % 32 == 0 && g.m >= 1024 && g.n >= 256) {
+  if (g.k % 64 == 0 && g.m >= 1024 && g.n % 256 == 0) {
     const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
     const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
     hipLaunchKernelGGL((gemm_f16_big_kernel<EPI>), dim3(grid), dim3(512), 0, st, g, tn, tm);

@@ -255,14 +255,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     // K % 64 == 0: LDS-DMA straight into the double buffer, next stage issued before the MFMAs
     // of the current one; __syncthreads() waits for the DMA (vmcnt) and the barrier.
     sim_stage_glds<_Float16, Cfg>(lds, g.w, n0, g.n - 1, g.a, m0, g.m - 1, g.k, 0, tid);
-    __syncthreads();
     for (int kc = 0; kc < nkc; ++kc) {
       const int cur = kc & 1;
+      sim_glds_retire_and_sync();  // stage kc landed for every wave; slot cur^1 is free
       if (kc + 1 < nkc)
         sim_stage_glds<_Float16, Cfg>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g.w, n0, g.n - 1, g.a, m0,
                                       g.m - 1, g.k, kc + 1, tid);
       sim_stage_mfma<_Float16, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_n, wave_m, lane);
-      __syncthreads();
     }
   } else {
     // ragged K: register-staged, zero-filled past K

@@ -149,6 +149,15 @@ __device__ __forceinline__ void sim_stage_glds(char* stage, const T* __restrict_
   }
 }
 
+// Retire every LDS-DMA this wave has issued, then meet the workgroup.  The explicit wait is
+// REQUIRED: hipcc (ROCm 7.2) tracks an LDS-DMA issued under a condition in a loop only up to the
+// back-edge and emits `s_waitcnt lgkmcnt(0); s_barrier` without the vmcnt wait there (seen in
+// sim_topk_scan: stale fragments, run-to-run different top-k).  asm is invisible to that pass.
+__device__ __forceinline__ void sim_glds_retire_and_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // MFMAs of one stage.  acc[gt][qt]: stream tile gt (0,1) x resident tile qt.
 template <typename T, typename Cfg, int QT>
 __device__ __forceinline__ void sim_stage_mfma(f32x16 (&acc)[2][QT], const char* stage,

@@ -66,8 +66,8 @@ struct ScanArgs {
   int d, k;
 };
 
-template <typename T, int KP, int QT, int WQ, int WGG>
-__global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
+template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS>
+__global__ __launch_bounds__(256, ((KP <= 16 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
   using Cfg = SimCfg<T, WGG, WQ, QT>;
   constexpr int EPS = SimElem<T>::kPerStage;
   constexpr int NSRC = 2 * WGG;  // lists per query inside a workgroup
@@ -125,19 +125,26 @@ __global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[gt][qt][i] = 0.f;
 
-  u32x4 regs[Cfg::NLOAD];
+  // Staging.  GLDS (d a multiple of the 128-B stage): LDS-DMA straight into the double buffer,
+  // stage step+1 issued right after the barrier that retires stage step.  Otherwise register
+  // staging one stage ahead with zero fill past d.
+  u32x4 regs[GLDS ? 1 : Cfg::NLOAD];
+  auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * Cfg::GM; };
   if (nsteps > 0) {
-    const int64_t row0 = a.row_begin + (int64_t)blockIdx.x * Cfg::GM;
-    sim_stage_load<T, Cfg>(regs, g, row0, g_last, q, q_row0, q_last, a.d, 0, tid);
-    sim_stage_store<Cfg>(regs, lds, tid);
+    if constexpr (GLDS) {
+      sim_stage_glds<T, Cfg>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+    } else {
+      sim_stage_load<T, Cfg>(regs, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+      sim_stage_store<Cfg>(regs, lds, tid);
+    }
   }
-  __syncthreads();
+  if constexpr (!GLDS) __syncthreads();
 
   int64_t tile_i = 0;  // index among my tiles
   int kc = 0;
   for (int64_t step = 0; step < nsteps; ++step) {
     const int cur = (int)(step & 1);
-    // prefetch next stage (possibly first chunk of my next tile)
+    // next stage (possibly first chunk of my next tile)
     int nkc_next = kc + 1;
     int64_t ntile_i = tile_i;
     if (nkc_next == nkc) {
@@ -145,17 +152,23 @@ __global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
       ntile_i = tile_i + 1;
     }
     const bool has_next = step + 1 < nsteps;
-    if (has_next) {
-      const int64_t row0n = a.row_begin + ((int64_t)blockIdx.x + ntile_i * gridDim.x) * Cfg::GM;
-      sim_stage_load<T, Cfg>(regs, g, row0n, g_last, q, q_row0, q_last, a.d, nkc_next, tid);
+    if constexpr (GLDS) {
+      sim_glds_retire_and_sync();  // DMA of stage `step` landed for every wave; slot cur^1 is free
+      if (has_next)
+        sim_stage_glds<T, Cfg>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q,
+                               q_row0, q_last, a.d, nkc_next, tid);
+      sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
+    } else {
+      if (has_next)
+        sim_stage_load<T, Cfg>(regs, g, tile_row0(ntile_i), g_last, q, q_row0, q_last, a.d, nkc_next, tid);
+      sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
+      if (has_next) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
     }
-    sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
-    if (has_next) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
 
     if (kc == nkc - 1) {
       // ---- per-tile epilogue: scale the 16 scores of each 32x32 tile, mask the ones
       //      above the lane's threshold, then pop candidates in row order into the list
-      const int64_t row0 = a.row_begin + ((int64_t)blockIdx.x + tile_i * gridDim.x) * Cfg::GM;
+      const int64_t row0 = tile_row0(tile_i);
 #pragma unroll
       for (int gt = 0; gt < 2; ++gt) {
         const int64_t rbase = row0 + wave_g * 64 + gt * 32 + 4 * h;
@@ -182,12 +195,16 @@ __global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
               cand = cand && ((s < cval[qt]) || (s == cval[qt] && (int)row > cidx[qt]));
             mask |= cand ? (1u << i) : 0u;
           }
-          // wave-uniform slot loop: acc[..][i] with a scalar i stays in registers
+          // common case behind the prefix floor: no lane has a candidate -> one ballot, no work.
+          // Otherwise a wave-uniform slot loop: acc[..][i] with a scalar i stays in registers
           // (movrel), a per-lane index would be lowered through scratch.
-          unsigned any = mask;
+          unsigned any = 0u;
+          if (__ballot(mask != 0u) != 0ull) {
+            any = mask;
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
-          any = __builtin_amdgcn_readfirstlane(any);
+            for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
+            any = __builtin_amdgcn_readfirstlane(any);
+          }
           while (any != 0u) {
             const int i = __builtin_ctz(any);
             any &= any - 1u;
@@ -202,10 +219,11 @@ __global__ __launch_bounds__(256) void sim_topk_scan(ScanArgs a) {
         }
       }
     }
-    __syncthreads();
+    if constexpr (!GLDS) __syncthreads();
     kc = nkc_next;
     tile_i = ntile_i;
   }
+  __syncthreads();  // every wave is done with the stage buffers before they are re-used below
 
   // ---- merge the NSRC lists of each query through LDS, one thread per query,
   //      QR queries per round
@@ -502,7 +520,10 @@ Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
 
 template <typename T, int KP, int QT, int WQ, int WGG>
 void launch_scan_cfg(const ScanArgs& a, int grid_x, int grid_y, hipStream_t st) {
-  hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+  if (a.d % SimElem<T>::kPerStage == 0)
+    hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG, true>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG, false>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
 }
 
 template <typename T>

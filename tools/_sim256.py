@@ -1,0 +1,7 @@
+import os, sys
+sys.path.insert(0, "/root/repo/tools")
+import torch
+from bench_sim import run
+run(256, 1_000_000, 768, 10, torch.float32, iters=5)
+run(64, 1_000_000, 768, 10, torch.float32, iters=5)
+run(64, 1_000_000, 768, 10, torch.float16, iters=5)

@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="query images per rank per step")
+    ap.add_argument("--batch", type=int, default=220, help="query images per rank per step")
     ap.add_argument("--gallery", type=int, default=1_000_000, help="total gallery rows (sharded over ranks)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--gallery-dtype", default="f32", choices=["f32", "f16"],

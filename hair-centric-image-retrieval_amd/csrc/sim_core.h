@@ -119,7 +119,7 @@ __device__ __forceinline__ void sim_stage_store(const u32x4 (&regs)[Cfg::NLOAD],
 // row still cover one whole 128-B line (cdna_hip_programming.md §5 caveat, rule 21).
 // No VGPR round trip and no ds_write: the register-staged path is bound by the
 // ds_write_b128 VGPR->LDS transfer (~79 B/clk/CU).  Requires d % (elements per stage) == 0.
-template <typename T, typename Cfg>
+template <typename T, typename Cfg, int AUX_STREAM = 0>
 __device__ __forceinline__ void sim_stage_glds(char* stage, const T* __restrict__ g, int64_t g_row0,
                                                int64_t g_last, const T* __restrict__ q,
                                                int64_t q_row0, int64_t q_last, int d, int kc,
@@ -143,9 +143,16 @@ __device__ __forceinline__ void sim_stage_glds(char* stage, const T* __restrict_
       qr = qr > q_last ? q_last : qr;
       src = q + qr * (int64_t)d + k0;
     }
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)src,
-        (__attribute__((address_space(3))) void*)(stage + (wave_base + Cfg::NT * i) * 16), 16, 0, 0);
+    // rows of one instruction are all stream rows or all resident rows (GM is a multiple of 8)
+    if ((Cfg::NT * i) / 8 + 63 / 8 < Cfg::GM || row < Cfg::GM)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(stage + (wave_base + Cfg::NT * i) * 16), 16, 0,
+          AUX_STREAM);
+    else
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(stage + (wave_base + Cfg::NT * i) * 16), 16, 0, 0);
   }
 }
 

@@ -21,6 +21,10 @@
 //            ceiling (val, idx) left by the previous pass.
 #include "sim_core.h"
 
+#ifndef HCIR_SCAN_AUX
+#define HCIR_SCAN_AUX 2  // cache policy of the once-read gallery stream: 2 = nt (non-temporal), +5 % GB/s
+#endif
+
 namespace {
 
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256, ((KP <= 16 && GLDS) ? 2 : 1)) void sim_topk_sc
   auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * Cfg::GM; };
   if (nsteps > 0) {
     if constexpr (GLDS) {
-      sim_stage_glds<T, Cfg>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+      sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
     } else {
       sim_stage_load<T, Cfg>(regs, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
       sim_stage_store<Cfg>(regs, lds, tid);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, ((KP <= 16 && GLDS) ? 2 : 1)) void sim_topk_sc
     if constexpr (GLDS) {
       sim_glds_retire_and_sync();  // DMA of stage `step` landed for every wave; slot cur^1 is free
       if (has_next)
-        sim_stage_glds<T, Cfg>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q,
+        sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q,
                                q_row0, q_last, a.d, nkc_next, tid);
       sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
     } else {

@@ -71,7 +71,7 @@ struct ScanArgs {
 };
 
 template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS>
-__global__ __launch_bounds__(256, ((KP <= 16 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
+__global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
   using Cfg = SimCfg<T, WGG, WQ, QT>;
   constexpr int EPS = SimElem<T>::kPerStage;
   constexpr int NSRC = 2 * WGG;  // lists per query inside a workgroup
@@ -467,7 +467,7 @@ constexpr int kMaxGridX = 512;  // 2 workgroups per CU; also <= 576 lists per me
 
 Plan make_plan(int64_t nq, int64_t ng, int k) {
   Plan p;
-  p.kp = k <= 16 ? 16 : 64;
+  p.kp = k <= 16 ? 16 : (k <= 32 ? 32 : 64);
   p.npass = (k + 63) / 64;
   if (p.kp == 64) {
     p.qb = 32;
@@ -535,6 +535,13 @@ void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
   const int grid_y = (int)hcir_cdiv(a.nq, p.qb);
   if (p.kp == 64) {
     launch_scan_cfg<T, 64, 1, 1, 4>(a, grid_x, grid_y, st);
+  } else if (p.kp == 32) {
+    if (p.qb == 32)
+      launch_scan_cfg<T, 32, 1, 1, 4>(a, grid_x, grid_y, st);
+    else if (p.qb == 64)
+      launch_scan_cfg<T, 32, 2, 1, 4>(a, grid_x, grid_y, st);
+    else
+      launch_scan_cfg<T, 32, 2, 2, 2>(a, grid_x, grid_y, st);
   } else if (p.qb == 32) {
     launch_scan_cfg<T, 16, 1, 1, 4>(a, grid_x, grid_y, st);
   } else if (p.qb == 64) {

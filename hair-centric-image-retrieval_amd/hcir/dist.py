@@ -34,7 +34,7 @@ class ShardedGallery:
     """One rank's shard of an L2-normalised gallery plus the collective search."""
 
     def __init__(self, shard: torch.Tensor, idx_base: int, group=None, ops=None,
-                 g_inv_norm: Optional[torch.Tensor] = None):
+                 g_inv_norm: Optional[torch.Tensor] = None, resident=None):
         if ops is None:
             from . import ops as _ops  # HIP path; raises if libhcir.so is missing
             ops = _ops
@@ -43,6 +43,9 @@ class ShardedGallery:
         self.idx_base = int(idx_base)
         self.group = group
         self.g_inv_norm = g_inv_norm
+        # optional hcir.gallery.ResidentGallery of the SAME shard: exact fp32 results through the
+        # fp16-mirror filter + exact refine + certified fallback
+        self.resident = resident
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
@@ -55,8 +58,11 @@ class ShardedGallery:
     def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
         """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""
         k_local = min(k, self.shard.shape[0])
-        val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
-                                     g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
+        if self.resident is not None and q_inv_norm is None and self.g_inv_norm is None:
+            val, idx = self.resident.search(q_all, k_local)
+        else:
+            val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
+                                         g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
         if k_local < k:  # tiny shard: pad with empty slots
             pad_v = torch.full((val.shape[0], k - k_local), float("-inf"), dtype=val.dtype, device=val.device)
             pad_i = torch.full((idx.shape[0], k - k_local), -1, dtype=idx.dtype, device=idx.device)

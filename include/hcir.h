@@ -86,6 +86,20 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
                   int64_t* out_idx, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* Exact re-scoring + certification of a candidate list ("exact by verification" search,
+ * DESIGN.md §3 "filtered search"; no reference equivalent).  cand_idx/cand_val [nq][kc] come from
+ * hcir_sim_topk on a reduced-precision MIRROR of the gallery (kc <= 64, sorted).  Every candidate is
+ * re-scored against the fp32 gallery `g` with the HCIR_F32 fmaf chain (bit-identical to
+ * hcir_sim_topk(HCIR_F32)), ranked (score desc, index asc) into out_val/out_idx [nq][k], and
+ * certified[i] = 1 iff  cand_val[i][kc-1] + err_bound[i] < exact k-th score, i.e. no row outside
+ * the candidate set can belong to the exact top-k, given |exact - mirror score| <= err_bound[i].
+ * The caller re-runs uncertified queries through hcir_sim_topk(HCIR_F32). */
+int hcir_topk_refine_f32(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
+                         const int64_t* cand_idx, const float* cand_val, int32_t kc, int32_t k,
+                         int64_t idx_base, const float* q_inv_norm, const float* g_inv_norm,
+                         const float* err_bound, float* out_val, int64_t* out_idx,
+                         int32_t* certified, void* stream);
+
 /* Merge `nlists` sorted top-k lists per query into one top-k_out list.
  * vals/idx layout: [nlists][nq][k_in].  Used for the per-shard merge after the
  * RCCL all-gather (no reference equivalent: the reference is single-GPU,

@@ -120,20 +120,48 @@ __device__ __forceinline__ void gemm_epilogue256(const GemmArgs& g, const f32x16
   gemm_epilogue_t<EPI, 4>(g, acc, m0, nbase, wave_m, lane);
 }
 
-// Epilogue of the 256 x 256 kernel: every wave transposes its 128(n) x 64(m) accumulator tile
-// through a private 8 KB piece of the LDS slot that the tile's last k-step has just released,
-// 64 B of n per row at a time, so that a lane ends up with 16 contiguous bytes of ONE output
-// row and 8 lanes cover a whole 128-B line (the direct layout gives every lane 8 B of a different
-// row: 1.6-1.9 TB/s effective on the fp16 outputs).  Bias / GELU / residual run on the
-// row-contiguous side.  [64 rows][128 B] image, 16-B chunks XOR-swizzled with row & 7.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f32x16 (&acc)[4][2],
-                                                     char* region, int64_t m0w, int nbase, int lane) {
+// Hide a value's origin from hipcc's waitcnt pass: after the explicit wait below, bias / scale
+// registers are "produced by asm", not by a pending global load.  Without this the per-iteration
+// control flow of the store loop makes the pass re-insert `s_waitcnt vmcnt(0)` before EVERY store
+// (it can no longer prove the bias load retired), which also drains the previous store: the 16-32
+// stores of a tile were fully serialised (seen in the .s; 40 % of GEMM time).
+__device__ __forceinline__ void launder(f32x4& v) { asm volatile("" : "+v"(v)); }
+
+template <int EPI, bool FULL>
+__device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, const f32x16 (&acc)[4][2],
+                                                          char* region, int64_t m0w, int nbase,
+                                                          int lane) {
   const int r = lane & 31, h = lane >> 5;
   constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 ||
                          EPI == HCIR_EPI_AFFINE_RELU_F16);
-  constexpr int NPASS = kF16 ? 2 : 4;     // 64 or 32 output features (128 B) per pass
+  constexpr bool kAffine = (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32);
+  constexpr int NPASS = kF16 ? 2 : 4;  // 64 or 32 output features (128 B) per pass
+  constexpr int NB = kF16 ? 2 : 1;     // float4 of bias per lane per pass
   const int rrow = lane >> 3, rchunk = lane & 7;
+
+  // per-lane bias / scale of every pass, loaded once, retired once, then laundered
+  f32x4 bias[NPASS][NB], scale[NPASS][NB];
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = nbase + pass * (kF16 ? 64 : 32) + rchunk * (kF16 ? 8 : 4) + 4 * j;
+      bias[pass][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      scale[pass][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (g.bias) bias[pass][j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if (kAffine || (EPI == HCIR_EPI_BIAS_RESID_F32 && g.scale))
+        scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      launder(bias[pass][j]);
+      launder(scale[pass][j]);
+    }
+
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     // ---- accumulators -> LDS (lane = output row m, registers = features n)
@@ -167,15 +195,6 @@ __device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f3
     // ---- LDS -> rows: lane = (row rrow + 8 it, 16-B chunk rchunk)
     if constexpr (kF16) {
       const int n = nbase + pass * 64 + rchunk * 8;
-      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, s0 = b0, s1 = b0;
-      if (g.bias) {
-        b0 = *reinterpret_cast<const f32x4*>(g.bias + n);
-        b1 = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-      }
-      if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
-        s0 = *reinterpret_cast<const f32x4*>(g.scale + n);
-        s1 = *reinterpret_cast<const f32x4*>(g.scale + n + 4);
-      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + rrow;
@@ -184,9 +203,9 @@ __device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f3
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float x = (float)v[e];
-          const float bb = e < 4 ? b0[e & 3] : b1[e & 3];
+          const float bb = bias[pass][e >> 2][e & 3];
           if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
-            x = fmaxf(__builtin_fmaf(x, e < 4 ? s0[e & 3] : s1[e & 3], bb), 0.f);
+            x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
           } else {
             x += bb;
             if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
@@ -194,37 +213,61 @@ __device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f3
           o[e] = (_Float16)x;
         }
         const int64_t m = m0w + row;
-        if (m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+        if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
       }
     } else {
       const int n = nbase + pass * 32 + rchunk * 4;
-      f32x4 b = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f};
-      if (g.bias) b = *reinterpret_cast<const f32x4*>(g.bias + n);
-      if (g.scale) sc = *reinterpret_cast<const f32x4*>(g.scale + n);
+      const f32x4 b = bias[pass][0], sc = scale[pass][0];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + rrow;
-        const int64_t mm = m0w + row;
-        f32x4 oldv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
-          if (mm < g.m) oldv = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+      for (int it0 = 0; it0 < 8; it0 += 4) {
+        // the four old-value loads of a group are issued back to back, so their waits are COUNTED
+        // (vmcnt(3), ...) and the stores of the previous group stay in flight
+        f32x4 oldv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t mm = m0w + (it0 + u) * 8 + rrow;
+          oldv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+            if (FULL || mm < g.m)
+              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+          }
         }
-        f32x4 v = *reinterpret_cast<const f32x4*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
-        if constexpr (EPI == HCIR_EPI_AFFINE_F32) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], b[e]);
-        } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+        for (int u = 0; u < 4; ++u) {
+          const int row = (it0 + u) * 8 + rrow;
+          const int64_t mm = m0w + row;
+          f32x4 v = *reinterpret_cast<const f32x4*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          if constexpr (EPI == HCIR_EPI_AFFINE_F32) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(sc[e], v[e] + b[e], oldv[e]);
-        } else {
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], b[e]);
+          } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(sc[e], v[e] + b[e], oldv[u][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+          }
+          if (FULL || mm < g.m) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + mm * g.ldo + n) = v;
         }
-        const int64_t m = m0w + row;
-        if (m < g.m) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + m * g.ldo + n) = v;
       }
     }
   }
+}
+
+// Epilogue of the 256 x 256 kernel: every wave transposes its 128(n) x 64(m) accumulator tile
+// through a private 8 KB piece of the LDS slot that the tile's last k-step has just released,
+// 128 B of one output row at a time, so that a lane ends up with 16 contiguous bytes of ONE output
+// row and 8 lanes cover a whole 128-B line (the direct layout gives every lane 8 B of a different
+// row: 1.6-1.9 TB/s effective on the fp16 outputs).  Bias / GELU / residual run on the
+// row-contiguous side.  [64 rows][128 B] image, 16-B chunks XOR-swizzled with row & 7.
+// Full tiles (all 64 rows of the wave inside M) take a branch-free path.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f32x16 (&acc)[4][2],
+                                                     char* region, int64_t m0w, int nbase, int lane) {
+  if (m0w + 64 <= g.m)
+    gemm_epilogue256_lds_impl<EPI, true>(g, acc, region, m0w, nbase, lane);
+  else
+    gemm_epilogue256_lds_impl<EPI, false>(g, acc, region, m0w, nbase, lane);
 }
 
 template <int EPI, bool GLDS>

@@ -4,8 +4,10 @@
 // nn.MultiheadAttention inside torchvision's EncoderBlock (HP/src/main_backbone.py:554):
 //   out = softmax((q * scale) k^T) v   per (batch, head), head_dim 64.
 //
-// One workgroup per (b, head); wave w owns query rows 32w .. 32w+31; K and V of the
-// head (T x 64 fp16 each) are staged ONCE into LDS and shared by all waves.
+// One 4-wave workgroup per (b, head); wave w owns query tiles w, w+4, ... (32 rows each);
+// K and V of the head (T x 64 fp16 each) are staged ONCE into LDS and shared by all waves.
+// Four waves (not one per query tile) keep two workgroups resident per CU, so one workgroup's
+// K/V staging latency hides under the other's MFMAs.
 //   S^T = K . Q^T   : MFMA 32x32x16 f16, keys on the MFMA row, queries on the column
 //                     -> a lane owns ONE query and holds its scores in registers:
 //                     row max / exp2 / row sum need one cross-half shuffle only.
@@ -30,7 +32,7 @@ struct AttnArgs {
 };
 
 template <int NKT>
-__global__ __launch_bounds__(64 * NKT) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int TP = 32 * NKT;
   __shared__ __attribute__((aligned(16))) char lds[2 * TP * 128];
   char* ks = lds;
@@ -47,120 +49,144 @@ __global__ __launch_bounds__(64 * NKT) void attn_fwd_kernel(AttnArgs a) {
   const _Float16* kg = base + (int64_t)a.h * 64;
   const _Float16* vg = base + (int64_t)2 * a.h * 64;
 
-  // ---- stage K and V (zero-filled past T) ----
-  for (int slot = tid; slot < TP * 8; slot += nthreads) {
-    const int key = slot >> 3, c = slot & 7;
-    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-    if (key < a.t) {
-      kv = *reinterpret_cast<const u32x4*>(kg + key * row_stride + c * 8);
-      vv = *reinterpret_cast<const u32x4*>(vg + key * row_stride + c * 8);
-    }
-    *reinterpret_cast<u32x4*>(ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4)) = kv;
-    *reinterpret_cast<u32x4*>(vs + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4)) = vv;
+  // ---- stage K and V by LDS-DMA: every piece of the head in flight at once, no VGPR round trip.
+  // The LDS destination of a wave instruction is linear (base + lane*16), so both swizzles are
+  // applied to the per-lane SOURCE chunk.  Keys past T are clamped to the last real key: finite
+  // data whose scores are masked to -inf (K) / whose probabilities are exactly 0 (V).
+  for (int slot0 = (tid & ~63); slot0 < TP * 8; slot0 += nthreads) {
+    const int slot = slot0 + lane;
+    const int key = slot >> 3, pc = slot & 7;
+    const int src_key = key < a.t ? key : a.t - 1;
+    const int kc = pc ^ ((key >> 1) & 7);
+    const int vc = pc ^ (((key >> 1) & 1) << 2);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(kg + src_key * row_stride + kc * 8),
+        (__attribute__((address_space(3))) void*)(ks + slot0 * 16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(vg + src_key * row_stride + vc * 8),
+        (__attribute__((address_space(3))) void*)(vs + slot0 * 16), 16, 0, 0);
   }
-
-  // ---- Q fragments straight from global: lane (q = r, half h) holds Q[q][16s + 8h .. +7]
-  const int q0 = wave * 32;
-  int qrow = q0 + r;
-  qrow = qrow < a.t ? qrow : a.t - 1;
-  f16x8 qf[4];
+  // Q fragments come straight from global: lane (q = r, half h) holds Q[q][16s + 8h .. +7].
+  // The first tile's fragments are requested together with the K/V DMA, the next tile's at the
+  // top of the current tile, so their latency is never exposed.
+  auto load_q = [&](int qt, f16x8 (&dst)[4]) {
+    int qrow = qt * 32 + r;
+    qrow = qrow < a.t ? qrow : a.t - 1;
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    qf[s] = *reinterpret_cast<const f16x8*>(qg + qrow * row_stride + 16 * s + 8 * h);
-
+    for (int s = 0; s < 4; ++s)
+      dst[s] = *reinterpret_cast<const f16x8*>(qg + qrow * row_stride + 16 * s + 8 * h);
+  };
+  f16x8 qf[4], qn[4];
+  load_q(wave, qf);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: see sim_glds_retire_and_sync()
   __syncthreads();
-
-  // ---- S^T = K . Q^T ----
-  f32x16 sc[NKT];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
-    const int key = kt * 32 + r;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int c = 2 * s + h;
-      const f16x8 kf =
-          *reinterpret_cast<const f16x8*>(ks + key * 128 + ((c ^ ((key >> 1) & 7)) << 4));
-      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kt], 0, 0, 0);
-    }
-  }
-
-  // ---- softmax over keys (registers + one cross-half exchange) ----
-  float mx = -__builtin_huge_valf();
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key = kt * 32 + acc_row(i, h);
-      const float s = key < a.t ? sc[kt][i] : -__builtin_huge_valf();
-      sc[kt][i] = s;
-      mx = fmaxf(mx, s);
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float p = __builtin_amdgcn_exp2f((sc[kt][i] - mx) * a.scale_log2e);
-      sc[kt][i] = p;
-      sum += p;
-    }
-  }
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
-
-  // ---- O^T = V^T . P ----
-  f32x16 oacc[2];
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
-
+  const int nqt = (a.t + 31) >> 5;
+  const float ninf = -__builtin_huge_valf();
   const int grp = lane >> 4, li = lane & 15;
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    // opaque per-iteration offset: stops hipcc from hoisting the ~80 loop-invariant LDS addresses
+    // out of the loop (that cost 256 VGPRs + scratch spills); they are re-derived from `lane` here
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const char* ksl = ks + opaque;
+    const char* vsl = vs + opaque;
+    const int q0 = qt * 32;
+    if (qt + 4 < nqt) load_q(qt + 4, qn);
+
+    // ---- S^T = K . Q^T ----
+    f32x16 sc[NKT];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f16x8 pf;
+      for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+      const int key = kt * 32 + r;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sc[kt][8 * s + j];
+      for (int s = 0; s < 4; ++s) {
+        const int c = 2 * s + h;
+        const f16x8 kf =
+            *reinterpret_cast<const f16x8*>(ksl + key * 128 + ((c ^ ((key >> 1) & 7)) << 4));
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kt], 0, 0, 0);
+      }
+    }
+
+    // ---- softmax over keys (registers + one cross-half exchange); only the LAST key tile can
+    //      hold keys >= T (TP - T < 32), so only it is masked
+    float mx = ninf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = (NKT - 1) * 32 + acc_row(i, h);
+      sc[NKT - 1][i] = key < a.t ? sc[NKT - 1][i] : ninf;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * a.scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], a.scale_log2e, -mxs));
+        sc[kt][i] = p;
+        sum += p;
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T = V^T . P ----
+    f32x16 oacc[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sc[kt][8 * s + j];
+#pragma unroll
+        for (int hdt = 0; hdt < 2; ++hdt) {
+          // transposed read: this lane supplies row (kb + li>>2), columns c0 + 4*(li&3) .. +3
+          const int c0 = 32 * hdt + 16 * (grp & 1) + 4 * (li & 3);
+          const int kb = 32 * kt + 16 * s + 4 * (grp >> 1) + (li >> 2);
+          f16x8 vf;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int key = kb + 8 * half;
+            const int col = c0 ^ (((key >> 1) & 1) << 5);
+            const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (fp16x4_t __attribute__((address_space(3)))*)(vsl + key * 128 + col * 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vf[4 * half + e] = (_Float16)v4[e];
+          }
+          oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[hdt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- store: lane owns query row q0 + r, registers hold head dims ----
+    const int q = q0 + r;
+    if (q < a.t) {
+      _Float16* orow = a.out + (b * a.t + q) * ((int64_t)a.h * 64) + head * 64;
 #pragma unroll
       for (int hdt = 0; hdt < 2; ++hdt) {
-        // transposed read: this lane supplies row (kb + li>>2), columns c0 + 4*(li&3) .. +3
-        const int c0 = 32 * hdt + 16 * (grp & 1) + 4 * (li & 3);
-        const int kb = 32 * kt + 16 * s + 4 * (grp >> 1) + (li >> 2);
-        f16x8 vf;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int key = kb + 8 * half;
-          const int col = c0 ^ (((key >> 1) & 1) << 5);
-          const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (fp16x4_t __attribute__((address_space(3)))*)(vs + key * 128 + col * 2));
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) vf[4 * half + e] = (_Float16)v4[e];
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
+          *reinterpret_cast<f16x4*>(orow + 32 * hdt + 8 * g4 + 4 * h) = o;
         }
-        oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[hdt], 0, 0, 0);
       }
     }
-  }
-
-  // ---- store: lane owns query row q0 + r, registers hold head dims ----
-  const int q = q0 + r;
-  if (q < a.t) {
-    _Float16* orow = a.out + (b * a.t + q) * ((int64_t)a.h * 64) + head * 64;
 #pragma unroll
-    for (int hdt = 0; hdt < 2; ++hdt) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
-        *reinterpret_cast<f16x4*>(orow + 32 * hdt + 8 * g4 + 4 * h) = o;
-      }
-    }
+    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
   }
 }
 
@@ -177,8 +203,8 @@ extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nqt = (t + 31) / 32;
   const dim3 grid((unsigned)(b * h));
-#define LAUNCH(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(64 * N), 0, st, a)
-  // the kernel is built for NKT key tiles AND NKT waves (one 32-row query tile each)
+#define LAUNCH(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), 0, st, a)
+  // the kernel is built for NKT key tiles; 4 waves walk the query tiles
   switch (nqt) {
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;

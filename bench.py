@@ -60,6 +60,16 @@ def vit_flops(b, t=197, d=768, mlp=3072, heads=12, layers=12):
     return gemm, attn, patch
 
 
+def gemm_algorithmic_bytes(b, t=197, d=768, mlp=3072):
+    """Average algorithmic HBM bytes of the four GEMM launches of a layer: A (fp16) + W (fp16) +
+    output (fp16 write for qkv / fc1, fp32 read-modify-write for proj / fc2)."""
+    m = b * t
+    per = []
+    for n, k, out_bytes in ((3 * d, d, 2), (d, d, 8), (mlp, d, 2), (d, mlp, 8)):
+        per.append(2 * m * k + 2 * n * k + out_bytes * m * n)
+    return sum(per) / len(per)
+
+
 def host_cores() -> int:
     """Cores this process may use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -228,6 +238,15 @@ def main():
         scan_esize = scan_g.element_size()
 
     if rank == 0:
+        # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
+        # process; the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
+        # passes of this same command is reported (profiles/r1_final_pmc_traffic.json), null if absent
+        gemm_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_final_pmc_traffic.json")) as f:
+                gemm_traffic = json.load(f).get("gemm_f16_big_kernel_avg_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         total_imgs = args.batch * world * args.steps
         gemm_f, attn_f, patch_f = vit_flops(args.batch)
         gemm_ms = sum(per_step.get(k, 0.0) for k in gemm_f)
@@ -251,9 +270,12 @@ def main():
                        "sim_mode": args.sim_mode,
                        "parallelism": f"gallery-shard{world}+query-dp{world}"},
             # dominant kernel by time: the fp16 MFMA GEMM (4 per layer x 12 layers per step)
-            "roofline": {"kernel": "gemm_f16_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f16_big_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",
                          "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": gemm_tf / MFMA_F16_PEAK_TF, "traffic": None,
+                         "frac": gemm_tf / MFMA_F16_PEAK_TF,
+                         "traffic": gemm_traffic if args.batch == 220 else None,
+                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, batch 220)",
+                         "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(args.batch),
                          "launches_per_step": ncalls_gemm, "avg_launch_ms": gemm_ms / max(ncalls_gemm, 1)},
             "roofline_sim_topk": {"kernel": "sim_topk_scan (+merge)", "bound": "hbm", "achieved": sim_gbs,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS,

@@ -127,11 +127,20 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
                              "--nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HCIR_BENCH_BACKEND=gloo is a REHEARSAL mode: several ranks share the visible GPU(s) and the
+    # (KB-sized) collectives hop through the host; it exists to exercise the N>1 control flow on a
+    # one-GPU box.  The driver's multi-GPU runs use the default: one GPU per rank, RCCL ("nccl").
+    backend = os.environ.get("HCIR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import hcir
     from hcir import ops
@@ -196,7 +205,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
 

@@ -30,6 +30,19 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_gather(tensor: torch.Tensor, world: int, group=None):
+    """all_gather of equal-shape tensors.  RCCL ("nccl") gathers device tensors in place; under the
+    gloo REHEARSAL backend (several ranks sharing one GPU, CPU tests) the payload hops through the host."""
+    if dist.get_backend(group) == "gloo" and tensor.is_cuda:
+        host = tensor.cpu()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host, group=group)
+        return [o.to(tensor.device) for o in out]
+    out = [torch.empty_like(tensor) for _ in range(world)]
+    dist.all_gather(out, tensor.contiguous(), group=group)
+    return out
+
+
 class ShardedGallery:
     """One rank's shard of an L2-normalised gallery plus the collective search."""
 
@@ -51,9 +64,7 @@ class ShardedGallery:
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return q_local
-        out = [torch.empty_like(q_local) for _ in range(self.world)]
-        dist.all_gather(out, q_local.contiguous(), group=self.group)
-        return torch.cat(out, 0)
+        return torch.cat(_all_gather(q_local, self.world, self.group), 0)
 
     def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
         """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""
@@ -69,8 +80,6 @@ class ShardedGallery:
             val, idx = torch.cat([val, pad_v], 1), torch.cat([idx, pad_i], 1)
         if self.world == 1:
             return val, idx
-        vals = [torch.empty_like(val) for _ in range(self.world)]
-        idxs = [torch.empty_like(idx) for _ in range(self.world)]
-        dist.all_gather(vals, val.contiguous(), group=self.group)
-        dist.all_gather(idxs, idx.contiguous(), group=self.group)
+        vals = _all_gather(val, self.world, self.group)
+        idxs = _all_gather(idx, self.world, self.group)
         return self.ops.topk_merge(torch.stack(vals, 0), torch.stack(idxs, 0), k)

@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--sim-mode", default="filtered", choices=["filtered", "exact", "f16"],
                     help="filtered = exact fp32 top-k via fp16-mirror scan + exact refine + certified fallback "
                          "(default); exact = full fp32 scan; f16 = fp16 gallery only (not exact)")
+    ap.add_argument("--resid", default="f16", choices=["f16", "f32"],
+                    help="storage type of the ViT residual stream (fp16: half the LayerNorm / residual-epilogue "
+                         "traffic, 1-cos vs the fp32 oracle 4e-7; fp32: 1e-7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="query images in the CPU baseline sample")
     return ap.parse_args()
@@ -143,7 +146,8 @@ def main():
             dist.init_process_group(backend)
 
     import hcir
-    from hcir import ops
+    from hcir import ops, vit_engine
+    vit_engine.DEFAULT_RESID_DTYPE = torch.float16 if args.resid == "f16" else torch.float32
     from hcir.dist import ShardedGallery, shard_bounds
     from hcir.main_backbone import SHAM2
     from hcir.profiling import EventProfiler
@@ -276,7 +280,7 @@ def main():
                                    f"{args.gallery} x 768 {args.gallery_dtype} gallery row-sharded over {world} GPU(s)",
                        "query_batch_per_gpu": args.batch, "global_query_batch": nq_all,
                        "gallery_rows": args.gallery, "gallery_dtype": args.gallery_dtype, "topk": args.topk,
-                       "sim_mode": args.sim_mode,
+                       "sim_mode": args.sim_mode, "residual_stream": args.resid,
                        "parallelism": f"gallery-shard{world}+query-dp{world}"},
             # dominant kernel by time: the fp16 MFMA GEMM (4 per layer x 12 layers per step)
             "roofline": {"kernel": "gemm_f16_big_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",

@@ -89,6 +89,16 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 
             o[e] = (_Float16)x;
           }
           *reinterpret_cast<f16x4*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+        } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
+          _Float16* p = static_cast<_Float16*>(g.out) + m * g.ldo + n;
+          const f16x4 oh = *reinterpret_cast<const f16x4*>(p);
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sc1 = g.scale ? g.scale[n + e] : 1.0f;
+            o[e] = (_Float16)__builtin_fmaf(sc1, v[e], (float)oh[e]);
+          }
+          *reinterpret_cast<f16x4*>(p) = o;
         } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
           float* p = static_cast<float*>(g.out) + m * g.ldo + n;
           f32x4 o = *reinterpret_cast<const f32x4*>(p);
@@ -133,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
                                                           int lane) {
   const int r = lane & 31, h = lane >> 5;
   constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 ||
-                         EPI == HCIR_EPI_AFFINE_RELU_F16);
+                         EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_BIAS_RESID_F16);
   constexpr bool kAffine = (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32);
   constexpr int NPASS = kF16 ? 2 : 4;  // 64 or 32 output features (128 B) per pass
   constexpr int NB = kF16 ? 2 : 1;     // float4 of bias per lane per pass
@@ -149,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
       bias[pass][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       scale[pass][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
       if (g.bias) bias[pass][j] = *reinterpret_cast<const f32x4*>(g.bias + n);
-      if (kAffine || (EPI == HCIR_EPI_BIAS_RESID_F32 && g.scale))
+      if (kAffine || ((EPI == HCIR_EPI_BIAS_RESID_F32 || EPI == HCIR_EPI_BIAS_RESID_F16) && g.scale))
         scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
     }
   }
@@ -196,24 +206,41 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
     if constexpr (kF16) {
       const int n = nbase + pass * 64 + rchunk * 8;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + rrow;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
-        f16x8 o;
+      for (int it0 = 0; it0 < 8; it0 += 4) {
+        // fp16 residual: the four old rows of a group are requested back to back (counted waits)
+        f16x8 oldh[4];
+        if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float x = (float)v[e];
-          const float bb = bias[pass][e >> 2][e & 3];
-          if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
-            x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
-          } else {
-            x += bb;
-            if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
+          for (int u = 0; u < 4; ++u) {
+            const int64_t mm = m0w + (it0 + u) * 8 + rrow;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oldh[u][e] = (_Float16)0.f;
+            if (FULL || mm < g.m)
+              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.out) + mm * g.ldo + n);
           }
-          o[e] = (_Float16)x;
         }
-        const int64_t m = m0w + row;
-        if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = (it0 + u) * 8 + rrow;
+          const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = (float)v[e];
+            const float bb = bias[pass][e >> 2][e & 3];
+            if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+              x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
+            } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
+              x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
+            } else {
+              x += bb;
+              if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
+            }
+            o[e] = (_Float16)x;
+          }
+          const int64_t m = m0w + row;
+          if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+        }
       }
     } else {
       const int n = nbase + pass * 32 + rchunk * 4;
@@ -479,12 +506,13 @@ struct PatchArgs {
   const _Float16* w;
   const float* bias;
   const float* pos;
-  float* tok;
+  void* tok;
   int64_t b;
   int c, h, w_px, gh, gw, d;
   float pos_mult;
 };
 
+template <typename TokT>
 __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles_n, int tiles_m) {
   using Cfg = GemmCfg;
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
@@ -556,7 +584,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles
     if (m >= mtot) continue;
     const int64_t bi = m / np;
     const int pi = (int)(m % np);
-    float* orow = p.tok + (bi * (np + 1) + 1 + pi) * (int64_t)p.d;
+    TokT* orow = static_cast<TokT*>(p.tok) + (bi * (np + 1) + 1 + pi) * (int64_t)p.d;
     const float* prow = p.pos + (int64_t)(1 + pi) * p.d;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -569,19 +597,27 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][4 * grp + e] + b[e] + p.pos_mult * ps[e];
-        *reinterpret_cast<f32x4*>(orow + n) = v;
+        if constexpr (sizeof(TokT) == 4) {
+          *reinterpret_cast<f32x4*>(orow + n) = v;
+        } else {
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+          *reinterpret_cast<f16x4*>(orow + n) = o;
+        }
       }
     }
   }
 }
 
+template <typename TokT>
 __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
-                               float pos_mult, int64_t b, int t, int d, float* __restrict__ tok) {
+                               float pos_mult, int64_t b, int t, int d, TokT* __restrict__ tok) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b * d) return;
   const int64_t bi = i / d;
   const int n = (int)(i % d);
-  tok[bi * t * (int64_t)d + n] = cls[n] + pos_mult * pos[n];
+  tok[bi * t * (int64_t)d + n] = (TokT)(cls[n] + pos_mult * pos[n]);
 }
 
 template <int EPI>
@@ -624,6 +660,7 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
     case HCIR_EPI_BIAS_F32: launch_gemm<HCIR_EPI_BIAS_F32>(g, st); break;
     case HCIR_EPI_AFFINE_RELU_F16: launch_gemm<HCIR_EPI_AFFINE_RELU_F16>(g, st); break;
     case HCIR_EPI_AFFINE_F32: launch_gemm<HCIR_EPI_AFFINE_F32>(g, st); break;
+    case HCIR_EPI_BIAS_RESID_F16: launch_gemm<HCIR_EPI_BIAS_RESID_F16>(g, st); break;
     default: return HCIR_ERR_UNSUPPORTED;
   }
   HCIR_LAUNCH_CHECK();
@@ -632,7 +669,7 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
 
 int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px, int32_t p,
                      const void* w_f16, const float* bias, const float* cls, const float* pos,
-                     float pos_mult, int32_t d, float* tok, void* stream) {
+                     float pos_mult, int32_t d, void* tok, int tok_dtype, void* stream) {
   HCIR_ENTER();
   if (!img || !w_f16 || !bias || !cls || !pos || !tok || b <= 0) return HCIR_ERR_INVALID;
   if (p != 16) return HCIR_ERR_UNSUPPORTED;  // ViT-*/16 only (ViT-L/14: DESIGN.md "next")
@@ -642,11 +679,19 @@ int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t 
   const int np = a.gh * a.gw;
   const int tiles_n = (int)hcir_cdiv(d, 128), tiles_m = (int)hcir_cdiv(b * np, 128);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(patch_embed_kernel, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n,
-                     tiles_m);
-  HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cls_row_kernel, dim3((unsigned)hcir_cdiv(b * d, 256)), dim3(256), 0, st, cls,
-                     pos, pos_mult, b, np + 1, d, tok);
+  if (tok_dtype != HCIR_F32 && tok_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
+  const dim3 cgrid((unsigned)hcir_cdiv(b * d, 256));
+  if (tok_dtype == HCIR_F32) {
+    hipLaunchKernelGGL(patch_embed_kernel<float>, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    HCIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cls_row_kernel<float>, cgrid, dim3(256), 0, st, cls, pos, pos_mult, b, np + 1, d,
+                       static_cast<float*>(tok));
+  } else {
+    hipLaunchKernelGGL(patch_embed_kernel<_Float16>, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    HCIR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cls_row_kernel<_Float16>, cgrid, dim3(256), 0, st, cls, pos, pos_mult, b, np + 1, d,
+                       static_cast<_Float16*>(tok));
+  }
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

@@ -8,16 +8,27 @@
 namespace {
 
 
+// 4 consecutive elements of a residual-stream row (fp32 or fp16 storage) as fp32.
+template <typename XT>
+__device__ __forceinline__ f32x4 load4(const XT* p) {
+  if constexpr (sizeof(XT) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+}
+
 // Loads row (d <= 2048, d % 4 == 0) as float4 per lane: element index 4*(lane + 64 j) + e.
-template <int NV>
-__device__ __forceinline__ void ln_row(const float* __restrict__ x, int d, int lane, f32x4 (&v)[NV],
+template <int NV, typename XT>
+__device__ __forceinline__ void ln_row(const XT* __restrict__ x, int d, int lane, f32x4 (&v)[NV],
                                        float& mean, float& rstd, float eps) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int k = 4 * (lane + 64 * j);
     v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (k < d) v[j] = *reinterpret_cast<const f32x4*>(x + k);
+    if (k < d) v[j] = load4<XT>(x + k);
     s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
   }
   mean = wave_sum(s) / (float)d;
@@ -36,8 +47,8 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ x, int d, int l
   rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, int64_t rows,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const XT* __restrict__ x, int64_t rows,
                                                             int d, int64_t ldx,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps,
@@ -47,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restr
   if (row >= rows) return;
   f32x4 v[NV];
   float mean, rstd;
-  ln_row<NV>(x + row * ldx, d, lane, v, mean, rstd, eps);
+  ln_row<NV, XT>(x + row * ldx, d, lane, v, mean, rstd, eps);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int k = 4 * (lane + 64 * j);
@@ -63,8 +74,8 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restr
 }
 
 // emb[b] = l2norm?( ln?( tok[b][0] ) )
-template <int NV>
-__global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__ tok, int64_t b, int t,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void cls_head_kernel(const XT* __restrict__ tok, int64_t b, int t,
                                                        int d, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps,
                                                        int l2, float* __restrict__ e32,
@@ -72,17 +83,17 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__
   const int lane = threadIdx.x & 63;
   const int64_t bi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bi >= b) return;
-  const float* x = tok + bi * t * (int64_t)d;
+  const XT* x = tok + bi * t * (int64_t)d;
   f32x4 v[NV];
   float mean = 0.f, rstd = 1.f;
   if (gamma) {
-    ln_row<NV>(x, d, lane, v, mean, rstd, eps);
+    ln_row<NV, XT>(x, d, lane, v, mean, rstd, eps);
   } else {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int k = 4 * (lane + 64 * j);
       v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (k < d) v[j] = *reinterpret_cast<const f32x4*>(x + k);
+      if (k < d) v[j] = load4<XT>(x + k);
     }
   }
   float ss = 0.f;
@@ -118,8 +129,8 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float* __restrict__
 }
 
 // out[b] = mean over tokens 1..t-1 of ln?(tok[b][i]); one workgroup (4 waves) per image.
-template <int NV>
-__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ tok, int t, int d,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void patch_mean_kernel(const XT* __restrict__ tok, int t, int d,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          float* __restrict__ out) {
@@ -130,17 +141,17 @@ __global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict
 #pragma unroll
   for (int j = 0; j < NV; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int i = 1 + wave; i < t; i += 4) {
-    const float* x = tok + (bi * t + i) * (int64_t)d;
+    const XT* x = tok + (bi * t + i) * (int64_t)d;
     f32x4 v[NV];
     float mean = 0.f, rstd = 1.f;
     if (gamma) {
-      ln_row<NV>(x, d, lane, v, mean, rstd, eps);
+      ln_row<NV, XT>(x, d, lane, v, mean, rstd, eps);
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int k = 4 * (lane + 64 * j);
         v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (k < d) v[j] = *reinterpret_cast<const f32x4*>(x + k);
+        if (k < d) v[j] = load4<XT>(x + k);
       }
     }
 #pragma unroll
@@ -183,50 +194,66 @@ __global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict
 
 extern "C" {
 
-int hcir_layernorm_f16(const float* x, int64_t rows, int32_t d, int64_t ldx, const float* gamma,
-                       const float* beta, float eps, void* y_f16, int64_t ldy, void* stream) {
+int hcir_layernorm_f16(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx,
+                       const float* gamma, const float* beta, float eps, void* y_f16, int64_t ldy,
+                       void* stream) {
   HCIR_ENTER();
   if (!x || !gamma || !beta || !y_f16 || rows <= 0 || d <= 0 || (d & 3) || d > 2048)
     return HCIR_ERR_INVALID;
   if (ldx < d || ldy < d || (ldx & 3) || (ldy & 3)) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)hcir_cdiv(rows, 4)), block(256);
-#define CALL(NV)                                                                                   \
-  hipLaunchKernelGGL(layernorm_f16_kernel<NV>, grid, block, 0, st, x, rows, d, ldx, gamma, beta, eps, \
-                     static_cast<_Float16*>(y_f16), ldy)
+  if (x_dtype != HCIR_F32 && x_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
+#define CALL(NV)                                                                                      \
+  if (x_dtype == HCIR_F32)                                                                            \
+    hipLaunchKernelGGL((layernorm_f16_kernel<NV, float>), grid, block, 0, st, (const float*)x, rows, d, \
+                       ldx, gamma, beta, eps, static_cast<_Float16*>(y_f16), ldy);                    \
+  else                                                                                                \
+    hipLaunchKernelGGL((layernorm_f16_kernel<NV, _Float16>), grid, block, 0, st, (const _Float16*)x,    \
+                       rows, d, ldx, gamma, beta, eps, static_cast<_Float16*>(y_f16), ldy)
   DISPATCH_NV(d, CALL);
 #undef CALL
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }
 
-int hcir_cls_head(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
-                  const float* beta, float eps, int l2_normalize, float* emb_f32, void* emb_f16,
-                  void* stream) {
+int hcir_cls_head(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_t d,
+                  const float* gamma, const float* beta, float eps, int l2_normalize, float* emb_f32,
+                  void* emb_f16, void* stream) {
   HCIR_ENTER();
   if (!tok || b <= 0 || t <= 0 || d <= 0 || (d & 3) || d > 2048) return HCIR_ERR_INVALID;
   if ((gamma == nullptr) != (beta == nullptr)) return HCIR_ERR_INVALID;
   if (!emb_f32 && !emb_f16) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)hcir_cdiv(b, 4)), block(256);
-#define CALL(NV)                                                                                \
-  hipLaunchKernelGGL(cls_head_kernel<NV>, grid, block, 0, st, tok, b, t, d, gamma, beta, eps,      \
-                     l2_normalize, emb_f32, static_cast<_Float16*>(emb_f16))
+  if (tok_dtype != HCIR_F32 && tok_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
+#define CALL(NV)                                                                                     \
+  if (tok_dtype == HCIR_F32)                                                                         \
+    hipLaunchKernelGGL((cls_head_kernel<NV, float>), grid, block, 0, st, (const float*)tok, b, t, d,   \
+                       gamma, beta, eps, l2_normalize, emb_f32, static_cast<_Float16*>(emb_f16));    \
+  else                                                                                               \
+    hipLaunchKernelGGL((cls_head_kernel<NV, _Float16>), grid, block, 0, st, (const _Float16*)tok, b, t, \
+                       d, gamma, beta, eps, l2_normalize, emb_f32, static_cast<_Float16*>(emb_f16))
   DISPATCH_NV(d, CALL);
 #undef CALL
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }
 
-int hcir_patch_mean(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
-                    const float* beta, float eps, float* out_f32, void* stream) {
+int hcir_patch_mean(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_t d,
+                    const float* gamma, const float* beta, float eps, float* out_f32, void* stream) {
   HCIR_ENTER();
   if (!tok || !out_f32 || b <= 0 || t <= 1 || d <= 0 || (d & 3) || d > 2048) return HCIR_ERR_INVALID;
   if ((gamma == nullptr) != (beta == nullptr)) return HCIR_ERR_INVALID;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define CALL(NV)                                                                                  \
-  hipLaunchKernelGGL(patch_mean_kernel<NV>, dim3((unsigned)b), dim3(256), 0, st, tok, t, d, gamma, \
-                     beta, eps, out_f32)
+  if (tok_dtype != HCIR_F32 && tok_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
+#define CALL(NV)                                                                                      \
+  if (tok_dtype == HCIR_F32)                                                                          \
+    hipLaunchKernelGGL((patch_mean_kernel<NV, float>), dim3((unsigned)b), dim3(256), 0, st,            \
+                       (const float*)tok, t, d, gamma, beta, eps, out_f32);                           \
+  else                                                                                                \
+    hipLaunchKernelGGL((patch_mean_kernel<NV, _Float16>), dim3((unsigned)b), dim3(256), 0, st,         \
+                       (const _Float16*)tok, t, d, gamma, beta, eps, out_f32)
   DISPATCH_NV(d, CALL);
 #undef CALL
   HCIR_LAUNCH_CHECK();

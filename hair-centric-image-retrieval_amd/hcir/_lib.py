@@ -20,7 +20,8 @@ CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libhcir.so")
 
 F32, F16, BF16 = 0, 1, 2
-EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_AFFINE_RELU_F16, EPI_AFFINE_F32 = range(6)
+EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_AFFINE_RELU_F16, EPI_AFFINE_F32, \
+    EPI_BIAS_RESID_F16 = range(7)
 
 _lib = None
 
@@ -41,14 +42,14 @@ SIGNATURES = {
     "hcir_topk_merge": (c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "hcir_ntxent_workspace_bytes": (c_sz, [c_i64, c_i32, c_int]),
     "hcir_ntxent_fwd": (c_int, [c_vp, c_vp, c_i64, c_i32, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "hcir_layernorm_f16": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "hcir_layernorm_f16": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
     "hcir_gemm_f16": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,
                               c_vp, c_i64, c_vp]),
     "hcir_patch_embed": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                 c_f32, c_i32, c_vp, c_vp]),
+                                 c_f32, c_i32, c_vp, c_int, c_vp]),
     "hcir_attn_fwd": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
-    "hcir_cls_head": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_int, c_vp, c_vp, c_vp]),
-    "hcir_patch_mean": (c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "hcir_cls_head": (c_int, [c_vp, c_int, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_int, c_vp, c_vp, c_vp]),
+    "hcir_patch_mean": (c_int, [c_vp, c_int, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
 }
 

@@ -19,6 +19,13 @@ from . import _lib
 from ._lib import HcirError, check
 
 
+# Residual-stream storage of engines built without an explicit choice.  fp32 is the conservative
+# default; set to torch.float16 (or HCIR_RESID=f16) to halve LayerNorm / residual-epilogue traffic.
+import os as _os
+
+DEFAULT_RESID_DTYPE = torch.float16 if _os.environ.get("HCIR_RESID", "f32") == "f16" else torch.float32
+
+
 @dataclass
 class VitLayer:
     ln1_w: torch.Tensor
@@ -80,7 +87,16 @@ def _p(t: Optional[torch.Tensor]):
 class VitEngine:
     """Device-resident fp16 weights + work buffers for one ViT; forward via the C ABI."""
 
-    def __init__(self, spec: VitSpec, device: torch.device):
+    def __init__(self, spec: VitSpec, device: torch.device, resid_dtype: torch.dtype = None):
+        # storage type of the residual stream: fp32 (conservative) or fp16 (half the LayerNorm /
+        # residual-epilogue HBM traffic; rounding 2^-11 per update ~ 1e-6 in embedding cosine)
+        if resid_dtype is None:
+            resid_dtype = DEFAULT_RESID_DTYPE
+        if resid_dtype not in (torch.float32, torch.float16):
+            raise HcirError("resid_dtype must be torch.float32 or torch.float16")
+        self.resid_dtype = resid_dtype
+        self._rt = _lib.F32 if resid_dtype == torch.float32 else _lib.F16
+        self._resid_epi = _lib.EPI_BIAS_RESID_F32 if resid_dtype == torch.float32 else _lib.EPI_BIAS_RESID_F16
         if device.type != "cuda":
             raise HcirError(f"VitEngine needs a HIP device, got {device} (no CPU fallback)")
         if spec.patch != 16:
@@ -112,7 +128,7 @@ class VitEngine:
         if bufs is None:
             m, d, dev = b * t, self.dim, self.device
             bufs = dict(
-                tok=torch.empty((b, t, d), dtype=torch.float32, device=dev),
+                tok=torch.empty((b, t, d), dtype=self.resid_dtype, device=dev),
                 ln=torch.empty((m, d), dtype=torch.float16, device=dev),
                 qkv=torch.empty((m, 3 * d), dtype=torch.float16, device=dev),
                 att=torch.empty((m, d), dtype=torch.float16, device=dev),
@@ -123,7 +139,7 @@ class VitEngine:
 
     # -- forward ---------------------------------------------------------------
     def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """x fp32 [B,3,H,W] on the HIP device -> fp32 token buffer [B,T,D] (engine-owned)."""
+        """x fp32 [B,3,H,W] on the HIP device -> token buffer [B,T,D] in resid_dtype (engine-owned)."""
         if not x.is_cuda:
             raise HcirError(f"input is on {x.device}; the hcir ViT runs on a HIP device only")
         if x.dtype != torch.float32:
@@ -141,11 +157,11 @@ class VitEngine:
         tok, ln, qkv, att, hid = w["tok"], w["ln"], w["qkv"], w["att"], w["hid"]
         check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, 16, self.conv_w.data_ptr(),
                                  self.conv_b.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(),
-                                 self.pos_mult, d, tok.data_ptr(), st), "hcir_patch_embed")
+                                 self.pos_mult, d, tok.data_ptr(), self._rt, st), "hcir_patch_embed")
         self._mark("patch_embed")
         scale = (d // self.heads) ** -0.5
         for l in self.layers:
-            check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
+            check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
                                        self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
             self._mark("layernorm")
             check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
@@ -155,9 +171,9 @@ class VitEngine:
                                   att.data_ptr(), st), "hcir_attn_fwd")
             self._mark("attn")
             check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
-                                  m, d, d, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
+                                  m, d, d, self._resid_epi, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
             self._mark("gemm_proj")
-            check(L.hcir_layernorm_f16(tok.data_ptr(), m, d, d, l.ln2_w.data_ptr(), l.ln2_b.data_ptr(),
+            check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln2_w.data_ptr(), l.ln2_b.data_ptr(),
                                        self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
             self._mark("layernorm")
             check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
@@ -165,7 +181,7 @@ class VitEngine:
                   "hcir_gemm_f16(fc1)")
             self._mark("gemm_fc1")
             check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
-                                  _p(l.ls2), m, d, self.mlp, _lib.EPI_BIAS_RESID_F32, tok.data_ptr(), d, st),
+                                  _p(l.ls2), m, d, self.mlp, self._resid_epi, tok.data_ptr(), d, st),
                   "hcir_gemm_f16(fc2)")
             self._mark("gemm_fc2")
         return tok
@@ -182,7 +198,7 @@ class VitEngine:
         bb = self.fln_b if final_norm else None
         if final_norm and g is None:
             raise HcirError("model has no final LayerNorm")
-        check(self.L.hcir_cls_head(tok.data_ptr(), b, t, d, _p(g), _p(bb), self.eps, int(l2_normalize),
+        check(self.L.hcir_cls_head(tok.data_ptr(), self._rt, b, t, d, _p(g), _p(bb), self.eps, int(l2_normalize),
                                    e32.data_ptr(), _p(e16), st), "hcir_cls_head")
         return (e32, e16) if want_f16 else e32
 
@@ -192,7 +208,7 @@ class VitEngine:
         out = torch.empty((b, d), dtype=torch.float32, device=tok.device)
         g = self.fln_w if final_norm else None
         bb = self.fln_b if final_norm else None
-        check(self.L.hcir_patch_mean(tok.data_ptr(), b, t, d, _p(g), _p(bb), self.eps, out.data_ptr(), st),
+        check(self.L.hcir_patch_mean(tok.data_ptr(), self._rt, b, t, d, _p(g), _p(bb), self.eps, out.data_ptr(), st),
               "hcir_patch_mean")
         return out
 
@@ -206,7 +222,7 @@ class EngineCache:
         self._key = None
 
     def get(self, params, make_spec, device: torch.device) -> VitEngine:
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (str(device), DEFAULT_RESID_DTYPE) + tuple((p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._key:
             self._engine = VitEngine(make_spec(), device)
             self._key = key

@@ -131,9 +131,9 @@ int hcir_ntxent_fwd(const void* z0, const void* z1, int64_t b, int32_t d, int dt
 /* LayerNorm over the last dim of fp32 rows -> fp16 rows.
  * nn.LayerNorm(D, eps=1e-6)   torchvision EncoderBlock.ln_1/ln_2 (HP/src/main_backbone.py:554)
  *                             models_vit.LayerNorm (HP/src/models_vit.py:23-27) */
-int hcir_layernorm_f16(const float* x, int64_t rows, int32_t d, int64_t ldx,
-                       const float* gamma, const float* beta, float eps, void* y_f16,
-                       int64_t ldy, void* stream);
+int hcir_layernorm_f16(const void* x, int x_dtype /* HCIR_F32 | HCIR_F16 residual stream */,
+                       int64_t rows, int32_t d, int64_t ldx, const float* gamma, const float* beta,
+                       float eps, void* y_f16, int64_t ldy, void* stream);
 
 /* Epilogues of hcir_gemm_f16:  acc = A[M,K] . W[N,K]^T  (fp32 accumulate) */
 typedef enum {
@@ -143,7 +143,9 @@ typedef enum {
                               /*   scale = LayerScale gamma or NULL)                            */
   HCIR_EPI_BIAS_F32 = 3,      /* out_f32 = acc + bias                                           */
   HCIR_EPI_AFFINE_RELU_F16 = 4,/* out_f16 = relu(acc * scale[n] + bias[n])  (proj-head Linear+BN+ReLU, eval) */
-  HCIR_EPI_AFFINE_F32 = 5     /* out_f32 = acc * scale[n] + bias[n]        (proj-head Linear+BN, eval)      */
+  HCIR_EPI_AFFINE_F32 = 5,    /* out_f32 = acc * scale[n] + bias[n]        (proj-head Linear+BN, eval)      */
+  HCIR_EPI_BIAS_RESID_F16 = 6 /* out_f16 += scale[n] * (acc + bias)        (fp16 residual stream; the add */
+                              /*   is done in fp32, one rounding to fp16)                              */
 } hcir_epilogue;
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T).  A, W fp16 row-major (W is the
@@ -161,10 +163,11 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
  *   tok[b][1 + p] = W . patch(b,p) + bias + pos_mult * pos[1 + p]
  * (HP/src/main_backbone.py:543-551 with pos_mult = 2, see DESIGN.md "double
  *  positional add"; HP/src/models_vit.py:42,48,229-233 with pos_mult = 1).
- * img fp32 [B][C][H][W]; w fp16 [D][C*P*P]; tok fp32 [B][1 + (H/P)(W/P)][D]. */
+ * img fp32 [B][C][H][W]; w fp16 [D][C*P*P]; tok [B][1 + (H/P)(W/P)][D] in tok_dtype
+ * (HCIR_F32 or HCIR_F16: the residual-stream storage type). */
 int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px,
                      int32_t p, const void* w_f16, const float* bias, const float* cls,
-                     const float* pos, float pos_mult, int32_t d, float* tok,
+                     const float* pos, float pos_mult, int32_t d, void* tok, int tok_dtype,
                      void* stream);
 
 /* Fused multi-head self-attention forward over packed qkv:
@@ -182,14 +185,15 @@ int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
  * (torchvision Encoder.ln + x[:,0]  HP/src/main_backbone.py:554,557;
  *  F.normalize  HP/src/classification_engine.py:50.)
  * emb_f32 [B][D]; emb_f16 optional. */
-int hcir_cls_head(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
-                  const float* beta, float eps, int l2_normalize, float* emb_f32,
-                  void* emb_f16, void* stream);
+int hcir_cls_head(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_t d,
+                  const float* gamma, const float* beta, float eps, int l2_normalize,
+                  float* emb_f32, void* emb_f16, void* stream);
 
 /* Mean over patch tokens 1..T-1 after the optional final LayerNorm
  * (pooled_patches of ViTWrapper.forward, HP/src/main_backbone.py:558-561). */
-int hcir_patch_mean(const float* tok, int64_t b, int32_t t, int32_t d, const float* gamma,
-                    const float* beta, float eps, float* out_f32, void* stream);
+int hcir_patch_mean(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_t d,
+                    const float* gamma, const float* beta, float eps, float* out_f32,
+                    void* stream);
 
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);

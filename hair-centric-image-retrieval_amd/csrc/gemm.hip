@@ -502,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
 //   a 16-B LDS slot = 8 consecutive pixels of one row (32 B of fp32 source).
 // ---------------------------------------------------------------------------
 struct PatchArgs {
+  int p, kreal, kpad;  // patch size, C*P*P, row length of the (zero-padded) weight matrix
   const float* img;
   const _Float16* w;
   const float* bias;
@@ -512,7 +513,7 @@ struct PatchArgs {
   float pos_mult;
 };
 
-template <typename TokT>
+template <typename TokT, bool P16>
 __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles_n, int tiles_m) {
   using Cfg = GemmCfg;
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles
   const int64_t m0 = (int64_t)tm * 128;
   const int np = p.gh * p.gw;
   const int64_t mtot = p.b * np;
-  const int kdim = p.c * 256;
+  const int kdim = p.kpad;
   const int nkc = kdim / 64;
 
   f32x16 acc[2][2];
@@ -552,15 +553,31 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles
         const int64_t bi = m / np;
         const int pi = (int)(m % np);
         const int py = pi / p.gw, px = pi % p.gw;
-        const int c = k0 >> 8, ky = (k0 >> 4) & 15, kx = k0 & 15;
-        const float* src = p.img + ((bi * p.c + c) * p.h + (py * 16 + ky)) * (int64_t)p.w_px + px * 16 + kx;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
         f16x8 v;
+        if constexpr (P16) {
+          const int c = k0 >> 8, ky = (k0 >> 4) & 15, kx = k0 & 15;
+          const float* src = p.img + ((bi * p.c + c) * p.h + (py * 16 + ky)) * (int64_t)p.w_px + px * 16 + kx;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = (_Float16)lo[e];
-          v[4 + e] = (_Float16)hi[e];
+          for (int e = 0; e < 4; ++e) {
+            v[e] = (_Float16)lo[e];
+            v[4 + e] = (_Float16)hi[e];
+          }
+        } else {
+          // any patch size: k = (c * P + ky) * P + kx, element by element, zero past C*P*P
+          const int pp = p.p * p.p;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            float x = 0.f;
+            if (k < p.kreal) {
+              const int c = k / pp, rem = k - c * pp;
+              const int ky = rem / p.p, kx = rem - ky * p.p;
+              x = p.img[((bi * p.c + c) * p.h + (py * p.p + ky)) * (int64_t)p.w_px + px * p.p + kx];
+            }
+            v[e] = (_Float16)x;
+          }
         }
         regs[i] = __builtin_bit_cast(u32x4, v);
       }
@@ -668,26 +685,34 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
 }
 
 int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px, int32_t p,
-                     const void* w_f16, const float* bias, const float* cls, const float* pos,
-                     float pos_mult, int32_t d, void* tok, int tok_dtype, void* stream) {
+                     const void* w_f16, int64_t ldw, const float* bias, const float* cls,
+                     const float* pos, float pos_mult, int32_t d, void* tok, int tok_dtype,
+                     void* stream) {
   HCIR_ENTER();
   if (!img || !w_f16 || !bias || !cls || !pos || !tok || b <= 0) return HCIR_ERR_INVALID;
-  if (p != 16) return HCIR_ERR_UNSUPPORTED;  // ViT-*/16 only (ViT-L/14: DESIGN.md "next")
-  if (c <= 0 || h % 16 || w_px % 16 || (d & 7)) return HCIR_ERR_INVALID;
-  PatchArgs a{img, static_cast<const _Float16*>(w_f16), bias, pos, tok, b, c, h, w_px, h / 16,
-              w_px / 16, d, pos_mult};
+  if (p <= 0 || p > 32 || c <= 0 || h % p || w_px % p || (d & 7)) return HCIR_ERR_INVALID;
+  const int kreal = c * p * p;
+  if (ldw < kreal || (ldw & 63)) return HCIR_ERR_INVALID;  // weight rows zero-padded to a multiple of 64
+  PatchArgs a{p, kreal, (int)ldw, img, static_cast<const _Float16*>(w_f16), bias, pos, tok, b, c, h, w_px,
+              h / p, w_px / p, d, pos_mult};
   const int np = a.gh * a.gw;
   const int tiles_n = (int)hcir_cdiv(d, 128), tiles_m = (int)hcir_cdiv(b * np, 128);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tok_dtype != HCIR_F32 && tok_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
   const dim3 cgrid((unsigned)hcir_cdiv(b * d, 256));
   if (tok_dtype == HCIR_F32) {
-    hipLaunchKernelGGL(patch_embed_kernel<float>, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    if (p == 16)
+      hipLaunchKernelGGL((patch_embed_kernel<float, true>), dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    else
+      hipLaunchKernelGGL((patch_embed_kernel<float, false>), dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
     HCIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(cls_row_kernel<float>, cgrid, dim3(256), 0, st, cls, pos, pos_mult, b, np + 1, d,
                        static_cast<float*>(tok));
   } else {
-    hipLaunchKernelGGL(patch_embed_kernel<_Float16>, dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    if (p == 16)
+      hipLaunchKernelGGL((patch_embed_kernel<_Float16, true>), dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
+    else
+      hipLaunchKernelGGL((patch_embed_kernel<_Float16, false>), dim3(tiles_n * tiles_m), dim3(256), 0, st, a, tiles_n, tiles_m);
     HCIR_LAUNCH_CHECK();
     hipLaunchKernelGGL(cls_row_kernel<_Float16>, cgrid, dim3(256), 0, st, cls, pos, pos_mult, b, np + 1, d,
                        static_cast<_Float16*>(tok));

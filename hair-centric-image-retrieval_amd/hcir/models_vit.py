@@ -186,6 +186,15 @@ def vit_large_patch16(**kwargs):
     return model
 
 
+def vit_large_patch14(**kwargs):
+    """ViT-L/14 (BASELINE config C5): not in the reference's models_vit.py (it has large/16 and
+    huge/14, :259-270); same constructor convention.  257 tokens, 16 heads of 64."""
+    model = VisionTransformer(
+        patch_size=14, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(LayerNorm, eps=1e-6), **kwargs)
+    return model
+
+
 def vit_huge_patch14(**kwargs):
     model = VisionTransformer(
         patch_size=14, embed_dim=1280, depth=32, num_heads=16, mlp_ratio=4, qkv_bias=True,

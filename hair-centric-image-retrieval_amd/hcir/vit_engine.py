@@ -99,14 +99,16 @@ class VitEngine:
         self._resid_epi = _lib.EPI_BIAS_RESID_F32 if resid_dtype == torch.float32 else _lib.EPI_BIAS_RESID_F16
         if device.type != "cuda":
             raise HcirError(f"VitEngine needs a HIP device, got {device} (no CPU fallback)")
-        if spec.patch != 16:
-            raise HcirError("hcir_patch_embed supports patch 16 (ViT-*/16) in this build")
         if spec.dim % spec.heads or spec.dim // spec.heads != 64:
             raise HcirError("hcir_attn_fwd supports head_dim 64")
         self.L = _lib.lib()
         self.device = device
         self.dim, self.heads, self.eps, self.pos_mult = spec.dim, spec.heads, float(spec.eps), float(spec.pos_mult)
-        self.conv_w = _f16(spec.conv_w.reshape(spec.dim, -1), device)
+        self.patch = int(spec.patch)
+        cw = _f16(spec.conv_w.reshape(spec.dim, -1), device)
+        kpad = (cw.shape[1] + 63) // 64 * 64           # rows zero-padded to the 64-wide k chunk
+        self.conv_w = torch.zeros((spec.dim, kpad), dtype=torch.float16, device=device)
+        self.conv_w[:, : cw.shape[1]] = cw
         self.conv_b = _f32(spec.conv_b, device)
         self.cls = _f32(spec.cls.reshape(-1), device)
         self.pos = _f32(spec.pos.reshape(-1, spec.dim), device)
@@ -146,16 +148,19 @@ class VitEngine:
             x = x.float()
         x = x.contiguous()
         b, c, hh, ww = x.shape
-        if hh % 16 or ww % 16:
+        ps = self.patch
+        if hh % ps or ww % ps:
             raise HcirError("image sides must be multiples of the patch size")
-        t = (hh // 16) * (ww // 16) + 1
+        t = (hh // ps) * (ww // ps) + 1
+        if t > 288:
+            raise HcirError("hcir_attn_fwd supports up to 288 tokens")
         if t != self.pos.shape[0]:
             raise HcirError(f"image gives {t} tokens but pos_embedding has {self.pos.shape[0]}")
         L, d, m = self.L, self.dim, b * t
         st = torch.cuda.current_stream(x.device).cuda_stream
         w = self._buffers(b, t)
         tok, ln, qkv, att, hid = w["tok"], w["ln"], w["qkv"], w["att"], w["hid"]
-        check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, 16, self.conv_w.data_ptr(),
+        check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, ps, self.conv_w.data_ptr(), self.conv_w.shape[1],
                                  self.conv_b.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(),
                                  self.pos_mult, d, tok.data_ptr(), self._rt, st), "hcir_patch_embed")
         self._mark("patch_embed")

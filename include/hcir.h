@@ -163,12 +163,14 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
  *   tok[b][1 + p] = W . patch(b,p) + bias + pos_mult * pos[1 + p]
  * (HP/src/main_backbone.py:543-551 with pos_mult = 2, see DESIGN.md "double
  *  positional add"; HP/src/models_vit.py:42,48,229-233 with pos_mult = 1).
- * img fp32 [B][C][H][W]; w fp16 [D][C*P*P]; tok [B][1 + (H/P)(W/P)][D] in tok_dtype
- * (HCIR_F32 or HCIR_F16: the residual-stream storage type). */
+ * img fp32 [B][C][H][W]; w fp16 [D][ldw], row = the C*P*P weights of one output feature in
+ * (c, ky, kx) order, zero-padded to ldw (a multiple of 64); tok [B][1 + (H/P)(W/P)][D] in
+ * tok_dtype (HCIR_F32 or HCIR_F16: the residual-stream storage type).  Any patch size P <= 32
+ * (P == 16 takes a vectorised path). */
 int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t w_px,
-                     int32_t p, const void* w_f16, const float* bias, const float* cls,
-                     const float* pos, float pos_mult, int32_t d, void* tok, int tok_dtype,
-                     void* stream);
+                     int32_t p, const void* w_f16, int64_t ldw, const float* bias,
+                     const float* cls, const float* pos, float pos_mult, int32_t d, void* tok,
+                     int tok_dtype, void* stream);
 
 /* Fused multi-head self-attention forward over packed qkv:
  *   qkv fp16 [B][T][3][H][hd]  (rows of the in_proj / qkv GEMM),

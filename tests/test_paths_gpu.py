@@ -109,6 +109,22 @@ def test_models_vit_layerscale():
     assert _cos_err(out[:, 0], ref[:, 0]) <= 1e-3
 
 
+def test_vit_large_patch14_config_c5_model():
+    """BASELINE config C5's model: ViT-L/14 (24 layers, dim 1024, 16 heads, 257 tokens), fp16 MFMA path."""
+    from hcir.models_vit import vit_large_patch14
+    torch.manual_seed(20)
+    m = vit_large_patch14(drop_path_rate=0.0, global_pool=True, init_values=None).eval()
+    _randomize(m, 21)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert tuple(sd["pos_embed"].shape) == (1, 257, 1024) and tuple(sd["patch_embed.proj.weight"].shape) == (1024, 3, 14, 14)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(22))
+    ref = ovit.models_vit_forward_features(sd, x, num_heads=16)
+    with torch.no_grad():
+        out = m.cuda().forward_features(x.cuda()).cpu()
+    assert out.shape == (2, 257, 1024)
+    assert _cos_err(out[:, 0], ref[:, 0]) <= 1e-3
+
+
 def test_mae_extract_features():
     from hcir.backbone import MAE, vit_base_patch16_224
     torch.manual_seed(9)

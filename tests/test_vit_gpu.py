@@ -142,11 +142,31 @@ def test_patch_embed(L, b, pos_mult, tdt):
     ref = torch.cat([cls.expand(b, 1, d), ref], 1) + pos_mult * pos
     tok = torch.empty(b, 197, d, device="cuda", dtype=tdt)
     args = [t_.cuda() for t_ in (img, w16.reshape(d, -1).contiguous(), bias, cls, pos)]
-    assert L.hcir_patch_embed(args[0].data_ptr(), b, 3, 224, 224, 16, args[1].data_ptr(), args[2].data_ptr(),
+    assert L.hcir_patch_embed(args[0].data_ptr(), b, 3, 224, 224, 16, args[1].data_ptr(), 768, args[2].data_ptr(),
                               args[3].data_ptr(), args[4].data_ptr(), pos_mult, d, tok.data_ptr(),
                               0 if tdt == torch.float32 else 1, _st()) == 0
     tol = 2e-4 if tdt == torch.float32 else 1e-3   # fp16 storage: one rounding, 2^-11 relative
     np.testing.assert_allclose(tok.float().cpu().numpy(), ref.numpy(), atol=tol * ref.abs().max().item(), rtol=0)
+
+
+def test_patch_embed_patch14(L):
+    """Generic patch size (ViT-L/14: P = 14, K = 588 zero-padded to 640, 257 tokens)."""
+    g = torch.Generator().manual_seed(14)
+    b, d, P = 2, 1024, 14
+    img = torch.randn(b, 3, 224, 224, generator=g)
+    w16 = (torch.randn(d, 3, P, P, generator=g) * 0.04).half()
+    bias, cls, pos = torch.randn(d, generator=g), torch.randn(d, generator=g), torch.randn(257, d, generator=g)
+    ref = F.conv2d(img.half().float(), w16.float(), bias, stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(b, 1, d), ref], 1) + pos
+    wp = torch.zeros(d, 640, dtype=torch.float16)
+    wp[:, :588] = w16.reshape(d, -1)
+    tok = torch.empty(b, 257, d, device="cuda")
+    args = [t_.cuda() for t_ in (img, wp, bias, cls, pos)]
+    assert L.hcir_patch_embed(args[0].data_ptr(), b, 3, 224, 224, P, args[1].data_ptr(), 640, args[2].data_ptr(),
+                              args[3].data_ptr(), args[4].data_ptr(), 1.0, d, tok.data_ptr(), 0, _st()) == 0
+    np.testing.assert_allclose(tok.cpu().numpy(), ref.numpy(), atol=2e-4 * ref.abs().max().item(), rtol=0)
+    assert L.hcir_patch_embed(args[0].data_ptr(), b, 3, 224, 224, P, args[1].data_ptr(), 588, args[2].data_ptr(),
+                              args[3].data_ptr(), args[4].data_ptr(), 1.0, d, tok.data_ptr(), 0, _st()) == -1
 
 
 def _randomize(model, seed):

@@ -12,6 +12,7 @@
 // 4 waves as 2(n) x 2(m), each wave 2x2 MFMA 32x32x16 tiles, LDS double buffer,
 // global loads register-staged one k-chunk ahead.
 #include "sim_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -137,8 +138,38 @@ __device__ __forceinline__ void gemm_epilogue256(const GemmArgs& g, const f32x16
 // stores of a tile were fully serialised (seen in the .s; 40 % of GEMM time).
 __device__ __forceinline__ void launder(f32x4& v) { asm volatile("" : "+v"(v)); }
 
-template <int EPI, bool FULL>
-__device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, const f32x16 (&acc)[4][2],
+// Accumulators of one wave tile (128 n x 64 m), either MFMA shape:
+//   MF16 = false: acc32[nt 0..3][mt 0..1], f32x16: n = 32nt + 8(i>>2) + 4(lane>>5) + (i&3), m = 32mt + (lane&31)
+//   MF16 = true : acc16[nt 0..7][mt 0..3], f32x4 : n = 16nt + 4(lane>>4) + i,            m = 16mt + (lane&15)
+template <bool MF16>
+struct WaveAcc;
+template <>
+struct WaveAcc<false> {
+  f32x16 a[4][2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[x][y][i] = 0.f;
+  }
+};
+template <>
+struct WaveAcc<true> {
+  f32x4 a[8][4];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[x][y][i] = 0.f;
+  }
+};
+
+template <int EPI, bool FULL, bool MF16>
+__device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, const WaveAcc<MF16>& acc,
                                                           char* region, int64_t m0w, int nbase,
                                                           int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -175,30 +206,56 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     // ---- accumulators -> LDS (lane = output row m, registers = features n)
+    if constexpr (!MF16) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = mt * 32 + r;
-      if constexpr (kF16) {
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 32 + r;
+        if constexpr (kF16) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int nt = 2 * pass + q;
+          for (int q = 0; q < 2; ++q) {
+            const int nt = 2 * pass + q;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+              f16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
+              const int chunk = q * 4 + grp;
+              *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
+            }
+          }
+        } else {
 #pragma unroll
           for (int grp = 0; grp < 4; ++grp) {
-            f16x4 o;
+            f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[nt][mt][4 * grp + e];
-            const int chunk = q * 4 + grp;
-            *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
+            for (int e = 0; e < 4; ++e) o[e] = acc.a[pass][mt][4 * grp + e];
+            const int chunk = 2 * grp + h;
+            *reinterpret_cast<f32x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4)) = o;
           }
         }
-      } else {
+      }
+    } else {
+      const int r16 = lane & 15, q16 = lane >> 4;
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-          f32x4 o;
+      for (int mt = 0; mt < 4; ++mt) {
+        const int row = mt * 16 + r16;
+        if constexpr (kF16) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[pass][mt][4 * grp + e];
-          const int chunk = 2 * grp + h;
-          *reinterpret_cast<f32x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4)) = o;
+          for (int q = 0; q < 4; ++q) {   // 64 features per pass = 4 n-tiles of 16
+            const int nt = 4 * pass + q;
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+            const int chunk = 2 * q + (q16 >> 1);
+            *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {   // 32 features per pass = 2 n-tiles of 16
+            const int nt = 2 * pass + q;
+            const int chunk = 4 * q + q16;
+            *reinterpret_cast<f32x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4)) = acc.a[nt][mt];
+          }
         }
       }
     }
@@ -288,13 +345,13 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 // row: 1.6-1.9 TB/s effective on the fp16 outputs).  Bias / GELU / residual run on the
 // row-contiguous side.  [64 rows][128 B] image, 16-B chunks XOR-swizzled with row & 7.
 // Full tiles (all 64 rows of the wave inside M) take a branch-free path.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const f32x16 (&acc)[4][2],
+template <int EPI, bool MF16>
+__device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const WaveAcc<MF16>& acc,
                                                      char* region, int64_t m0w, int nbase, int lane) {
   if (m0w + 64 <= g.m)
-    gemm_epilogue256_lds_impl<EPI, true>(g, acc, region, m0w, nbase, lane);
+    gemm_epilogue256_lds_impl<EPI, true, MF16>(g, acc, region, m0w, nbase, lane);
   else
-    gemm_epilogue256_lds_impl<EPI, false>(g, acc, region, m0w, nbase, lane);
+    gemm_epilogue256_lds_impl<EPI, false, MF16>(g, acc, region, m0w, nbase, lane);
 }
 
 template <int EPI, bool GLDS>
@@ -373,7 +430,7 @@ struct G256 {
   static constexpr int NLOAD = ROWS * 8 / NT;    // 16-B pieces per thread per stage = 8
 };
 
-template <int EPI>
+template <int EPI, bool MF16>
 __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int tiles_n, int tiles_m) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G256::STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -428,13 +485,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     }
   };
 
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  WaveAcc<MF16> acc;
+  acc.zero();
 
   if (nsteps > 0) {
     set_sources(0);
@@ -451,26 +503,58 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     const char* st = lds + (step & 1) * G256::STAGE_BYTES;
     const bool do_issue = step + 1 < nsteps;
     const int islot = (step + 1) & 1;
+    if constexpr (!MF16) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = 2 * ks + h;
-      u32x4 af[4], bf[2];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = 2 * ks + h;
+        u32x4 af[4], bf[2];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        af[nt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_n * 128 + nt * 32 + r, chunk));
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_m * 64 + mt * 32 + r, chunk));
-      if (do_issue && ks < 2) {  // four of the eight DMA pieces of stage step+1 per early k-substep
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * ks + i);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
+          af[nt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_n * 128 + nt * 32 + r, chunk));
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-              __builtin_bit_cast(f16x8, af[nt]), __builtin_bit_cast(f16x8, bf[mt]), acc[nt][mt], 0, 0, 0);
+          bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_m * 64 + mt * 32 + r, chunk));
+        if (do_issue && ks < 2) {  // four of the eight DMA pieces of stage step+1 per early k-substep
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * ks + i);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc.a[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(f16x8, af[nt]), __builtin_bit_cast(f16x8, bf[mt]), acc.a[nt][mt], 0, 0, 0);
+      }
+    } else {
+      // 16x16x32: lane (r16 = lane&15, kq = lane>>4) holds row r16, k = 32*ks2 + 8*kq .. +7
+      const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int chunk = 4 * ks2 + kq;
+        u32x4 bf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_m * 64 + mt * 16 + r16, chunk));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          u32x4 af[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            af[q] = *reinterpret_cast<const u32x4*>(
+                st + sim_slot_off(wave_n * 128 + (4 * half + q) * 16 + r16, chunk));
+          if (do_issue && ks2 == 0) {  // the eight DMA pieces of stage step+1 in the first 32-k substep
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * half + i);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              acc.a[4 * half + q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                  __builtin_bit_cast(f16x8, af[q]), __builtin_bit_cast(f16x8, bf[mt]), acc.a[4 * half + q][mt],
+                  0, 0, 0);
+        }
+      }
     }
     if (do_issue) issue_advance();
 
@@ -481,14 +565,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       // all waves are done reading slot step&1 (their MFMAs have consumed it) after this barrier;
       // the slot stays free until the DMA of stage step+2 is issued behind the next step's barrier
       __builtin_amdgcn_s_barrier();
-      gemm_epilogue256_lds<EPI>(g, acc, lds + (step & 1) * G256::STAGE_BYTES + wave * 8192,
-                                m0 + wave_m * 64, n0 + wave_n * 128, lane);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+      gemm_epilogue256_lds<EPI, MF16>(g, acc, lds + (step & 1) * G256::STAGE_BYTES + wave * 8192,
+                                      m0 + wave_m * 64, n0 + wave_n * 128, lane);
+      acc.zero();
       kc = 0;
       ++ti;
     }
@@ -642,7 +721,11 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (g.k % 64 == 0 && g.m >= 1024 && g.n % 256 == 0) {
     const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
     const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
-    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+    static const bool mf16 = [] { const char* e = getenv("HCIR_GEMM_MFMA"); return !(e && e[0] == '3'); }();
+    if (mf16)
+      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+    else
+      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
     return;
   }
   const int tiles_n = (int)hcir_cdiv(g.n, 128), tiles_m = (int)hcir_cdiv(g.m, 128);

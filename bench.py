@@ -63,12 +63,12 @@ def vit_flops(b, t=197, d=768, mlp=3072, heads=12, layers=12):
     return gemm, attn, patch
 
 
-def gemm_algorithmic_bytes(b, t=197, d=768, mlp=3072):
+def gemm_algorithmic_bytes(b, resid_bytes=4, t=197, d=768, mlp=3072):
     """Average algorithmic HBM bytes of the four GEMM launches of a layer: A (fp16) + W (fp16) +
-    output (fp16 write for qkv / fc1, fp32 read-modify-write for proj / fc2)."""
+    output (fp16 write for qkv / fc1, residual-stream read-modify-write for proj / fc2)."""
     m = b * t
     per = []
-    for n, k, out_bytes in ((3 * d, d, 2), (d, d, 8), (mlp, d, 2), (d, mlp, 8)):
+    for n, k, out_bytes in ((3 * d, d, 2), (d, d, 2 * resid_bytes), (mlp, d, 2), (d, mlp, 2 * resid_bytes)):
         per.append(2 * m * k + 2 * n * k + out_bytes * m * n)
     return sum(per) / len(per)
 
@@ -180,6 +180,11 @@ def main():
     x = torch.randn((args.batch, 3, 224, 224), generator=torch.Generator(device=dev).manual_seed(1 + rank),
                     device=dev)
 
+    # Software pipeline: the certification check of batch i (one host sync) is taken AFTER batch
+    # i+1's embed + scan have been enqueued, so the GPU never idles behind the host; every batch is
+    # finished (certified, fallback, cross-rank merge) inside the timed region.
+    pending = [None]
+
     def step(prof=None):
         with torch.no_grad():
             e32, e16 = vit.forward_cls(x, l2_normalize=True, want_f16=True)
@@ -189,13 +194,23 @@ def main():
             q_all = gallery.gather_queries(q)
             if prof:
                 prof.mark("allgather_q")
-            out = gallery.search(q_all, args.topk)
+            handle = gallery.search_begin(q_all, args.topk)
             if prof:
                 prof.mark("sim_topk+merge")
+            out = gallery.search_finish(pending[0]) if pending[0] is not None else None
+            pending[0] = handle
+            if prof:
+                prof.mark("certify+gather_prev")
             return out
+
+    def drain():
+        out = gallery.search_finish(pending[0]) if pending[0] is not None else None
+        pending[0] = None
+        return out
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,6 +218,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -221,6 +237,7 @@ def main():
     for _ in range(nprof):
         prof.start()
         step(prof)
+    drain()
     eng.prof = None
     summ = prof.summary()
     per_step = {k: v["ms"] / nprof for k, v in summ.items()}
@@ -286,9 +303,9 @@ def main():
             "roofline": {"kernel": "gemm_f16_big_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",
                          "achieved": gemm_tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                          "frac": gemm_tf / MFMA_F16_PEAK_TF,
-                         "traffic": gemm_traffic if args.batch == 220 else None,
+                         "traffic": gemm_traffic if (args.batch == 220 and args.resid == "f16") else None,
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, batch 220)",
-                         "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(args.batch),
+                         "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(args.batch, 2 if args.resid == "f16" else 4),
                          "launches_per_step": ncalls_gemm, "avg_launch_ms": gemm_ms / max(ncalls_gemm, 1)},
             "roofline_sim_topk": {"kernel": "sim_topk_scan (+merge)", "bound": "hbm", "achieved": sim_gbs,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS,

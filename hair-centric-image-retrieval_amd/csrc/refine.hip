@@ -20,7 +20,8 @@ struct RefineArgs {
   const float* g;
   const int64_t* cand_idx;  // [nq][kc] global indices (idx_base included), < 0 = empty
   const float* cand_val;    // [nq][kc] filter scores, sorted descending
-  const float* err;         // [nq] bound on |exact - filter score| for this query
+  const float* err;         // [nq] bound on |exact - filter score| for this query, or null:
+  float eg, g16max, g32max, gamma;  //   then E_i is derived here from the mirror's constants (gallery.py)
   const float* qn;          // optional inverse norms (score = (dot * gn) * qn)
   const float* gn;
   float* out_val;
@@ -35,6 +36,23 @@ __global__ __launch_bounds__(256) void topk_refine_kernel(RefineArgs a) {
   const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= a.nq) return;
   const float ninf = -__builtin_huge_valf();
+  // E_i = ||q|| eg + ||q - q~|| g16max + gamma (||q|| g32max + ||q~|| g16max), q~ = fp16(q)
+  float err_i = 0.f;
+  if (a.err) {
+    err_i = a.err[qi];
+  } else {
+    const float* qr0 = a.q + qi * (int64_t)a.d;
+    float s_q = 0.f, s_d = 0.f, s_h = 0.f;
+    for (int k = lane; k < a.d; k += 64) {
+      const float x = qr0[k];
+      const float xh = (float)(_Float16)x;
+      s_q = __builtin_fmaf(x, x, s_q);
+      s_d = __builtin_fmaf(x - xh, x - xh, s_d);
+      s_h = __builtin_fmaf(xh, xh, s_h);
+    }
+    const float nq_ = sqrtf(wave_sum(s_q)), nd_ = sqrtf(wave_sum(s_d)), nh_ = sqrtf(wave_sum(s_h));
+    err_i = (nq_ * a.eg + nd_ * a.g16max + a.gamma * (nq_ * a.g32max + nh_ * a.g16max)) * 1.01f + 1e-7f;
+  }
   float sc = ninf;
   int64_t id = -1;
   if (lane < a.kc) id = a.cand_idx[qi * a.kc + lane];
@@ -95,7 +113,7 @@ __global__ __launch_bounds__(256) void topk_refine_kernel(RefineArgs a) {
       ok = 1;  // the filter returned every row it has: nothing outside the candidate set
     } else {
       const float t = a.cand_val[qi * a.kc + a.kc - 1];
-      ok = (kth_mask != 0ull) && (t + a.err[qi] < vk);
+      ok = (kth_mask != 0ull) && (t + err_i < vk);
     }
     a.certified[qi] = ok;
   }
@@ -106,15 +124,23 @@ __global__ __launch_bounds__(256) void topk_refine_kernel(RefineArgs a) {
 extern "C" int hcir_topk_refine_f32(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
                                     const int64_t* cand_idx, const float* cand_val, int32_t kc,
                                     int32_t k, int64_t idx_base, const float* q_inv_norm,
-                                    const float* g_inv_norm, const float* err_bound, float* out_val,
-                                    int64_t* out_idx, int32_t* certified, void* stream) {
+                                    const float* g_inv_norm, const float* err_bound,
+                                    const float* mirror_consts, float* out_val, int64_t* out_idx,
+                                    int32_t* certified, void* stream) {
   HCIR_ENTER();
-  if (!q || !g || !cand_idx || !cand_val || !err_bound || !out_val || !out_idx || !certified)
+  if (!q || !g || !cand_idx || !cand_val || (!err_bound && !mirror_consts) || !out_val || !out_idx ||
+      !certified)
     return HCIR_ERR_INVALID;
   if (nq <= 0 || ng <= 0 || d <= 0 || (d & 7) || kc <= 0 || kc > 64 || k <= 0 || k > kc)
     return HCIR_ERR_INVALID;
-  RefineArgs a{q, g, cand_idx, cand_val, err_bound, q_inv_norm, g_inv_norm, out_val, out_idx,
-               certified, nq, idx_base, d, kc, k};
+  RefineArgs a{q, g, cand_idx, cand_val, err_bound, 0.f, 0.f, 0.f, 0.f, q_inv_norm, g_inv_norm, out_val,
+               out_idx, certified, nq, idx_base, d, kc, k};
+  if (!err_bound) {  // host array {eg, g16max, g32max, gamma}: constants of the gallery mirror
+    a.eg = mirror_consts[0];
+    a.g16max = mirror_consts[1];
+    a.g32max = mirror_consts[2];
+    a.gamma = mirror_consts[3];
+  }
   hipLaunchKernelGGL(topk_refine_kernel, dim3((unsigned)hcir_cdiv(nq, 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   HCIR_LAUNCH_CHECK();

@@ -38,7 +38,7 @@ SIGNATURES = {
     "hcir_sim_topk": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_int, c_vp, c_vp, c_i64,
                               c_vp, c_vp, c_vp, c_sz, c_vp]),
     "hcir_topk_refine_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp,
-                                     c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "hcir_topk_merge": (c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "hcir_ntxent_workspace_bytes": (c_sz, [c_i64, c_i32, c_int]),
     "hcir_ntxent_fwd": (c_int, [c_vp, c_vp, c_i64, c_i32, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -66,14 +66,20 @@ class ShardedGallery:
             return q_local
         return torch.cat(_all_gather(q_local, self.world, self.group), 0)
 
-    def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
-        """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""
+    def search_begin(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
+        """Enqueue the local scan of this rank's shard; returns a handle for search_finish."""
         k_local = min(k, self.shard.shape[0])
         if self.resident is not None and q_inv_norm is None and self.g_inv_norm is None:
-            val, idx = self.resident.search(q_all, k_local)
-        else:
-            val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
-                                         g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
+            return (self.resident.search_begin(q_all, k_local), k, k_local)
+        val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
+                                     g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
+        return ((val, idx), k, k_local)
+
+    def search_finish(self, handle):
+        """Certify / fall back locally, then all-gather the per-shard top-k and merge (same result on
+        every rank, identical to a single scan of the whole gallery)."""
+        local, k, k_local = handle
+        val, idx = local.finish() if hasattr(local, "finish") else local
         if k_local < k:  # tiny shard: pad with empty slots
             pad_v = torch.full((val.shape[0], k - k_local), float("-inf"), dtype=val.dtype, device=val.device)
             pad_i = torch.full((idx.shape[0], k - k_local), -1, dtype=idx.dtype, device=idx.device)
@@ -83,3 +89,7 @@ class ShardedGallery:
         vals = _all_gather(val, self.world, self.group)
         idxs = _all_gather(idx, self.world, self.group)
         return self.ops.topk_merge(torch.stack(vals, 0), torch.stack(idxs, 0), k)
+
+    def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
+        """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""
+        return self.search_finish(self.search_begin(q_all, k, q_inv_norm))

@@ -56,6 +56,8 @@ class ResidentGallery:
             u = 2.0 ** -24
             gamma = d * u / (1.0 - d * u)
             self._eg, self._g16max, self._g32max, self._gamma = egmax, gmax16, gmax32, gamma
+            import ctypes
+            self._consts = (ctypes.c_float * 4)(egmax, gmax16, gmax32, gamma)  # host array for the refine kernel
 
     # ---- exact fp32 scan ---------------------------------------------------------------------
     def search_exact(self, q32: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -70,28 +72,48 @@ class ResidentGallery:
             + self._gamma * (qn * self._g32max + qf.norm(dim=1) * self._g16max)
         return (e * 1.01 + 1e-7).contiguous()
 
-    def search(self, q32: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Exact fp32 top-k of q32 against the gallery (identical to search_exact)."""
+    def search_begin(self, q32: torch.Tensor, k: int) -> "PendingSearch":
+        """Launch filter + refine (asynchronous, no host sync) and return a handle; `finish()` checks
+        the certification flags (one host sync) and re-runs uncertified queries through the exact scan.
+        Splitting the two lets a caller enqueue its NEXT batch's work before it blocks on the flags,
+        so the GPU never idles behind the check (bench.py does exactly that)."""
         if self.mirror is None or k > FILTER_KC - 2 or self.g32.shape[0] <= FILTER_KC:
-            return self.search_exact(q32, k)
+            val, idx = self.search_exact(q32, k)
+            return PendingSearch(self, q32, k, val, idx, None)
         ops._dev(q32, "q")
         nq, d = q32.shape
         q16 = q32.to(self.mirror.dtype)
         cval, cidx = ops.sim_topk(q16, self.mirror, FILTER_KC, idx_base=self.idx_base)
-        err = self.err_bound(q32, q16)
         val = torch.empty((nq, k), dtype=torch.float32, device=q32.device)
         idx = torch.empty((nq, k), dtype=torch.int64, device=q32.device)
         cert = torch.empty(nq, dtype=torch.int32, device=q32.device)
         check(_lib.lib().hcir_topk_refine_f32(
             q32.data_ptr(), nq, self.g32.data_ptr(), self.g32.shape[0], d, cidx.data_ptr(), cval.data_ptr(),
-            FILTER_KC, k, self.idx_base, None, None, err.data_ptr(), val.data_ptr(), idx.data_ptr(),
+            FILTER_KC, k, self.idx_base, None, None, None, self._consts, val.data_ptr(), idx.data_ptr(),
             cert.data_ptr(), ops._stream(q32)), "hcir_topk_refine_f32")
-        bad = (cert == 0).nonzero().flatten()  # one host sync per batch: results are needed anyway
-        self.stats["calls"] += 1
-        self.stats["queries"] += nq
-        if bad.numel():
-            self.stats["fallback_queries"] += int(bad.numel())
-            bv, bi = self.search_exact(q32[bad].contiguous(), k)
-            val[bad] = bv
-            idx[bad] = bi
-        return val, idx
+        return PendingSearch(self, q32, k, val, idx, cert)
+
+    def search(self, q32: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact fp32 top-k of q32 against the gallery (identical to search_exact)."""
+        return self.search_begin(q32, k).finish()
+
+
+class PendingSearch:
+    """Result of ResidentGallery.search_begin: device tensors already enqueued; finish() certifies."""
+
+    def __init__(self, gallery, q32, k, val, idx, cert):
+        self.gallery, self.q32, self.k, self.val, self.idx, self.cert = gallery, q32, k, val, idx, cert
+
+    def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        g = self.gallery
+        if self.cert is not None:
+            bad = (self.cert == 0).nonzero().flatten()  # the one host sync of a batch
+            g.stats["calls"] += 1
+            g.stats["queries"] += self.q32.shape[0]
+            if bad.numel():
+                g.stats["fallback_queries"] += int(bad.numel())
+                bv, bi = g.search_exact(self.q32[bad].contiguous(), self.k)
+                self.val[bad] = bv
+                self.idx[bad] = bi
+            self.cert = None
+        return self.val, self.idx

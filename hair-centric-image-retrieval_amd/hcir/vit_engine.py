@@ -227,8 +227,16 @@ class EngineCache:
         self._key = None
 
     def get(self, params, make_spec, device: torch.device) -> VitEngine:
+        # cheap per-call check (first / last parameter), full fingerprint every 64th call: the
+        # fingerprint walks ~150 tensors (~0.1 ms of host time per forward otherwise)
+        self._calls = getattr(self, "_calls", 0) + 1
+        quick = (str(device), DEFAULT_RESID_DTYPE, params[0].data_ptr(), params[0]._version,
+                 params[-1].data_ptr(), params[-1]._version)
+        if self._engine is not None and quick == getattr(self, "_quick", None) and self._calls % 64:
+            return self._engine
         key = (str(device), DEFAULT_RESID_DTYPE) + tuple((p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._key:
             self._engine = VitEngine(make_spec(), device)
             self._key = key
+        self._quick = quick
         return self._engine

@@ -93,12 +93,15 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
  * hcir_sim_topk(HCIR_F32)), ranked (score desc, index asc) into out_val/out_idx [nq][k], and
  * certified[i] = 1 iff  cand_val[i][kc-1] + err_bound[i] < exact k-th score, i.e. no row outside
  * the candidate set can belong to the exact top-k, given |exact - mirror score| <= err_bound[i].
- * The caller re-runs uncertified queries through hcir_sim_topk(HCIR_F32). */
+ * err_bound is a device array [nq], or NULL: then E_i is computed in the kernel from the HOST array
+ * mirror_consts = {max_j ||g_j - g~_j||, max_j ||g~_j||, max_j ||g_j||, gamma_d} of an fp16 mirror
+ * (derivation: hcir/gallery.py).  The caller re-runs uncertified queries through
+ * hcir_sim_topk(HCIR_F32). */
 int hcir_topk_refine_f32(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
                          const int64_t* cand_idx, const float* cand_val, int32_t kc, int32_t k,
                          int64_t idx_base, const float* q_inv_norm, const float* g_inv_norm,
-                         const float* err_bound, float* out_val, int64_t* out_idx,
-                         int32_t* certified, void* stream);
+                         const float* err_bound, const float* mirror_consts, float* out_val,
+                         int64_t* out_idx, int32_t* certified, void* stream);
 
 /* Merge `nlists` sorted top-k lists per query into one top-k_out list.
  * vals/idx layout: [nlists][nq][k_in].  Used for the per-shard merge after the

@@ -77,6 +77,33 @@ def test_error_bound_holds():
     assert err.max() < 2e-3 and diff.max() < err.max()          # and it is not vacuous
 
 
+def test_in_kernel_bound_matches_python_bound():
+    """hcir_topk_refine_f32 derives E_i itself from the mirror constants; it must certify exactly the
+    queries the documented (python) bound certifies."""
+    from hcir import _lib, ops
+    from hcir.gallery import FILTER_KC, ResidentGallery
+    q, g = _unit((64, 256), 10), _unit((20000, 256), 11)
+    g[100:400] = g[50] + 2e-4 * np.random.default_rng(0).standard_normal((300, 256)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    q[:8] = g[50] + 0.02 * np.random.default_rng(1).standard_normal((8, 256)).astype(np.float32)
+    gal = ResidentGallery(torch.from_numpy(g).cuda())
+    qd = torch.from_numpy(q).cuda()
+    q16 = qd.half()
+    cval, cidx = ops.sim_topk(q16, gal.mirror, FILTER_KC)
+    outs = []
+    for err in (gal.err_bound(qd, q16), None):
+        val = torch.empty((64, 10), device="cuda")
+        idx = torch.empty((64, 10), dtype=torch.int64, device="cuda")
+        cert = torch.empty(64, dtype=torch.int32, device="cuda")
+        assert _lib.lib().hcir_topk_refine_f32(
+            qd.data_ptr(), 64, gal.g32.data_ptr(), 20000, 256, cidx.data_ptr(), cval.data_ptr(), FILTER_KC, 10, 0,
+            None, None, None if err is None else err.data_ptr(), None if err is not None else gal._consts,
+            val.data_ptr(), idx.data_ptr(), cert.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        outs.append((val.cpu(), idx.cpu(), cert.cpu()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][1], outs[1][1])
+    assert 0 < int((outs[1][2] == 0).sum()) < 64      # the planted cloud defeats some queries, not all
+
+
 def test_sharded_gallery_uses_resident():
     from hcir.dist import ShardedGallery
     from hcir.gallery import ResidentGallery

@@ -255,3 +255,41 @@ def test_hair_encoder_retrieve(golden_dir, tmp_path):
     feats = enc.extract_features(x.cuda())
     ref = ovit.models_vit_forward_features({k: v.cpu() for k, v in enc.model.state_dict().items()}, x)[:, 0]
     assert _cos_err(feats.cpu(), ref) <= 1e-3
+
+
+def test_knn_cli_end_to_end(tmp_path):
+    """The reference's CLI contract on a synthetic folder: same flags, same output file; the sweep
+    stops with sklearn's ValueError at the first k larger than the training set (k = 642 is in the
+    reference's default sweep, HP/src/classification_engine.py:71)."""
+    import importlib.util
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "knn_cli_e2e", os.path.join(root, "hair-centric-image-retrieval_amd", "knn_classification.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    rng = np.random.default_rng(0)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    rows = {"train": [], "test": []}
+    for split, n in (("train", 48), ("test", 12)):
+        for i in range(n):
+            cls = i % 3
+            arr = rng.integers(0, 255, (240, 250, 3), dtype=np.uint8)
+            arr[..., cls] = 255 - arr[..., cls] // 4          # class-dependent colour cast
+            name = f"{split}_{i}.png"
+            Image.fromarray(arr).save(img_dir / name)
+            rows[split].append(f"{name},{cls}")
+    for split in rows:
+        (tmp_path / f"{split}.csv").write_text("id,class\n" + "\n".join(rows[split]) + "\n")
+    args = cli.parse_args(["--mode", "SHAM", "--model", "resnet18", "--eval_type", "knn", "--batch_size", "16",
+                           "--num_workers", "0", "--device", "cuda", "--save_path", str(tmp_path / "out"),
+                           "--train_annotation", str(tmp_path / "train.csv"),
+                           "--test_annotation", str(tmp_path / "test.csv"), "--img_dir", str(img_dir)])
+    cli.set_seed(args.seed)
+    with pytest.raises(ValueError, match="n_neighbors"):
+        cli.main(args)
+    txt = (tmp_path / "out" / "SHAM_resnet18_embedding" / "knn_evaluation_results.txt").read_text()
+    for k in (5, 10, 20, 27, 30, 40):
+        assert f"Results for k={k}\n" in txt
+    assert "Results for k=642" not in txt and "Confusion Matrix:" in txt

@@ -293,3 +293,46 @@ def test_knn_cli_end_to_end(tmp_path):
     for k in (5, 10, 20, 27, 30, 40):
         assert f"Results for k={k}\n" in txt
     assert "Results for k=642" not in txt and "Confusion Matrix:" in txt
+
+
+def test_index_flat_l2(tmp_path):
+    """faiss.IndexFlatL2 semantics (squared L2, ascending, -1 / +inf padding) on hcir_sim_topk, checked
+    against float64 numpy; unit-norm rows (the reference's use) and general rows."""
+    from hcir import index as hidx
+    rng = np.random.default_rng(4)
+    for normalise, d in ((True, 768), (False, 100)):
+        g = rng.standard_normal((3000, d)).astype(np.float32) * (1.0 if normalise else 3.0)
+        q = rng.standard_normal((17, d)).astype(np.float32)
+        if normalise:
+            hidx.normalize_L2(g)
+            hidx.normalize_L2(q)
+            assert np.allclose(np.linalg.norm(g, axis=1), 1.0, atol=1e-6)
+        ix = hidx.IndexFlatL2(d)
+        ix.add(g[:1000])
+        ix.add(g[1000:])
+        assert ix.ntotal == 3000 and ix.is_trained
+        D, I = ix.search(q, 10)
+        ref = ((q[:, None, :].astype(np.float64) - g[None].astype(np.float64)) ** 2).sum(-1)
+        order = np.argsort(ref, axis=1, kind="stable")[:, :11]
+        rd = np.take_along_axis(ref, order, 1)
+        tol = 2e-5 * max(1.0, rd.max())
+        np.testing.assert_allclose(D, rd[:, :10], atol=tol, rtol=0)
+        safe = (rd[:, 1:] - rd[:, :-1]) > 4 * tol
+        ok = np.concatenate([np.ones((17, 1), bool), safe[:, :9]], 1) & safe[:, :10]
+        np.testing.assert_array_equal(I[ok], order[:, :10][ok])
+        if normalise:      # on unit vectors D = 2 - 2 cos: the ranking the reference relies on
+            np.testing.assert_allclose(D, 2 - 2 * np.take_along_axis(q.astype(np.float64) @ g.T.astype(np.float64), I, 1),
+                                       atol=1e-5)
+    small = hidx.IndexFlatL2(d)
+    small.add(g[:7])
+    D, I = small.search(q[:2], 10)                      # k > ntotal: padded like faiss
+    assert (I[:, 7:] == -1).all() and np.isinf(D[:, 7:]).all() and (I[:, :7] >= 0).all()
+    with pytest.raises(ValueError):                     # the scan's k limit (HCIR_TOPK_MAX)
+        ix.search(q[:2], 2000)
+    hidx.write_index(ix, str(tmp_path / "hair.index"))
+    ix2 = hidx.read_index(str(tmp_path / "hair.index"))
+    D2, I2 = ix2.search(q, 10)
+    D1, I1 = ix.search(q, 10)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+    hidx.save_paths(["a.png", "b.png"], str(tmp_path / "paths.pkl"))
+    assert hidx.load_paths(str(tmp_path / "paths.pkl")) == ["a.png", "b.png"]

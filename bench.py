@@ -54,11 +54,15 @@ def parse():
 
 
 def vit_flops(b, t=197, d=768, mlp=3072, heads=12, layers=12):
+    """Algorithmic flops of one embedding forward as the engine runs it: `layers - 1` full blocks and a
+    last block whose attention queries / proj / MLP are computed for the class-token rows only."""
     m = b * t
-    gemm = {"gemm_qkv": 2 * m * 3 * d * d, "gemm_proj": 2 * m * d * d, "gemm_fc1": 2 * m * mlp * d,
+    full = {"gemm_qkv": 2 * m * 3 * d * d, "gemm_proj": 2 * m * d * d, "gemm_fc1": 2 * m * mlp * d,
             "gemm_fc2": 2 * m * d * mlp}
-    gemm = {k: v * layers for k, v in gemm.items()}
-    attn = 4 * b * heads * t * t * (d // heads) * layers
+    cls = {"gemm_qkv": 2 * m * 3 * d * d, "gemm_proj": 2 * b * d * d, "gemm_fc1": 2 * b * mlp * d,
+           "gemm_fc2": 2 * b * d * mlp}
+    gemm = {k: full[k] * (layers - 1) + cls[k] for k in full}
+    attn = 4 * b * heads * t * t * (d // heads) * (layers - 1) + 4 * b * heads * 1 * t * (d // heads)
     patch = 2 * b * (t - 1) * d * d
     return gemm, attn, patch
 

@@ -26,8 +26,9 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct AttnArgs {
   const _Float16* qkv;  // [B][T][3][H][64]
-  _Float16* out;        // [B][T][H*64]
+  _Float16* out;        // [B][NQ][H*64]
   int t, h;
+  int nq;               // query rows computed per (b, head): T, or fewer (CLS-only last layer: 1)
   float scale_log2e;
 };
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   load_q(wave, qf);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: see sim_glds_retire_and_sync()
   __syncthreads();
-  const int nqt = (a.t + 31) >> 5;
+  const int nqt = (a.nq + 31) >> 5;
   const float ninf = -__builtin_huge_valf();
   const int grp = lane >> 4, li = lane & 15;
 
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     // ---- store: lane owns query row q0 + r, registers hold head dims ----
     const int q = q0 + r;
-    if (q < a.t) {
-      _Float16* orow = a.out + (b * a.t + q) * ((int64_t)a.h * 64) + head * 64;
+    if (q < a.nq) {
+      _Float16* orow = a.out + (b * a.nq + q) * ((int64_t)a.h * 64) + head * 64;
 #pragma unroll
       for (int hdt = 0; hdt < 2; ++hdt) {
 #pragma unroll
@@ -193,12 +194,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }  // namespace
 
 extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
-                             float scale, void* out, void* stream) {
+                             float scale, int32_t nq, void* out, void* stream) {
   HCIR_ENTER();
-  if (!qkv || !out || b <= 0 || t <= 0 || h <= 0) return HCIR_ERR_INVALID;
+  if (!qkv || !out || b <= 0 || t <= 0 || h <= 0 || nq <= 0 || nq > t) return HCIR_ERR_INVALID;
   if (hd != 64 || t > 288) return HCIR_ERR_UNSUPPORTED;
   if (b * h > 0x7fffffff) return HCIR_ERR_INVALID;
-  AttnArgs a{static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), t, h,
+  AttnArgs a{static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), t, h, nq,
              scale * 1.44269504088896340736f};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nqt = (t + 31) / 32;

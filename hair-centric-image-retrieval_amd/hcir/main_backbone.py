@@ -137,7 +137,7 @@ class ViTWrapper(nn.Module):
         F.normalize and an fp16 copy for the similarity scan."""
         self._check_no_grad()
         eng = self.engine(x.device)
-        tok = eng.forward_tokens(x)
+        tok = eng.forward_tokens(x, cls_only_last=True)   # only the class token is consumed
         return eng.cls_embedding(tok, final_norm=True, l2_normalize=l2_normalize, want_f16=want_f16)
 
 

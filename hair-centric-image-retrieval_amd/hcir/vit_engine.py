@@ -135,13 +135,22 @@ class VitEngine:
                 qkv=torch.empty((m, 3 * d), dtype=torch.float16, device=dev),
                 att=torch.empty((m, d), dtype=torch.float16, device=dev),
                 hid=torch.empty((m, self.mlp), dtype=torch.float16, device=dev),
+                # compact buffers of the CLS-only last block (B rows)
+                att_c=torch.empty((b, d), dtype=torch.float16, device=dev),
+                ln_c=torch.empty((b, d), dtype=torch.float16, device=dev),
+                hid_c=torch.empty((b, self.mlp), dtype=torch.float16, device=dev),
             )
             self._bufs = {key: bufs}  # keep one shape resident
         return bufs
 
     # -- forward ---------------------------------------------------------------
-    def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """x fp32 [B,3,H,W] on the HIP device -> token buffer [B,T,D] in resid_dtype (engine-owned)."""
+    def forward_tokens(self, x: torch.Tensor, cls_only_last: bool = False) -> torch.Tensor:
+        """x fp32 [B,3,H,W] on the HIP device -> token buffer [B,T,D] in resid_dtype (engine-owned).
+
+        cls_only_last: the caller consumes only the class token (extract_features).  The last block
+        then computes K and V for every token but attention queries, proj, LN2 and the MLP for the
+        class-token rows only (B rows instead of B*T): same arithmetic for those rows, ~1/12 of the
+        forward saved.  Patch-token rows of the returned buffer are then those BEFORE the last block."""
         if not x.is_cuda:
             raise HcirError(f"input is on {x.device}; the hcir ViT runs on a HIP device only")
         if x.dtype != torch.float32:
@@ -165,30 +174,54 @@ class VitEngine:
                                  self.pos_mult, d, tok.data_ptr(), self._rt, st), "hcir_patch_embed")
         self._mark("patch_embed")
         scale = (d // self.heads) ** -0.5
-        for l in self.layers:
+        last = len(self.layers) - 1
+        for li, l in enumerate(self.layers):
+            cls_only = cls_only_last and li == last
             check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
                                        self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
             self._mark("layernorm")
             check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
                                   _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d, st), "hcir_gemm_f16(qkv)")
             self._mark("gemm_qkv")
-            check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale,
-                                  att.data_ptr(), st), "hcir_attn_fwd")
-            self._mark("attn")
-            check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
-                                  m, d, d, self._resid_epi, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
-            self._mark("gemm_proj")
-            check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln2_w.data_ptr(), l.ln2_b.data_ptr(),
-                                       self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
-            self._mark("layernorm")
-            check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
-                                  self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
-                  "hcir_gemm_f16(fc1)")
-            self._mark("gemm_fc1")
-            check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
-                                  _p(l.ls2), m, d, self.mlp, self._resid_epi, tok.data_ptr(), d, st),
-                  "hcir_gemm_f16(fc2)")
-            self._mark("gemm_fc2")
+            if not cls_only:
+                check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale, t,
+                                      att.data_ptr(), st), "hcir_attn_fwd")
+                self._mark("attn")
+                check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
+                                      m, d, d, self._resid_epi, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
+                self._mark("gemm_proj")
+                check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln2_w.data_ptr(),
+                                           l.ln2_b.data_ptr(), self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+                self._mark("layernorm")
+                check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
+                                      self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
+                      "hcir_gemm_f16(fc1)")
+                self._mark("gemm_fc1")
+                check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
+                                      _p(l.ls2), m, d, self.mlp, self._resid_epi, tok.data_ptr(), d, st),
+                      "hcir_gemm_f16(fc2)")
+                self._mark("gemm_fc2")
+            else:
+                # class-token rows only: row b of the compact buffers <-> tok[b][0] (row stride t*d)
+                att_c, ln_c, hid_c = w["att_c"], w["ln_c"], w["hid_c"]
+                check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale, 1,
+                                      att_c.data_ptr(), st), "hcir_attn_fwd(cls)")
+                self._mark("attn")
+                check(L.hcir_gemm_f16(att_c.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
+                                      b, d, d, self._resid_epi, tok.data_ptr(), t * d, st), "hcir_gemm_f16(proj,cls)")
+                self._mark("gemm_proj")
+                check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, b, d, t * d, l.ln2_w.data_ptr(),
+                                           l.ln2_b.data_ptr(), self.eps, ln_c.data_ptr(), d, st),
+                      "hcir_layernorm_f16(cls)")
+                self._mark("layernorm")
+                check(L.hcir_gemm_f16(ln_c.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, b,
+                                      self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid_c.data_ptr(), self.mlp, st),
+                      "hcir_gemm_f16(fc1,cls)")
+                self._mark("gemm_fc1")
+                check(L.hcir_gemm_f16(hid_c.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
+                                      _p(l.ls2), b, d, self.mlp, self._resid_epi, tok.data_ptr(), t * d, st),
+                      "hcir_gemm_f16(fc2,cls)")
+                self._mark("gemm_fc2")
         return tok
 
     def cls_embedding(self, tok: torch.Tensor, final_norm: bool, l2_normalize: bool,

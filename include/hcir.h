@@ -177,13 +177,15 @@ int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t 
 
 /* Fused multi-head self-attention forward over packed qkv:
  *   qkv fp16 [B][T][3][H][hd]  (rows of the in_proj / qkv GEMM),
- *   out fp16 [B][T][H*hd] = softmax((q * scale) k^T) v   per (b, head).
+ *   out fp16 [B][nq][H*hd] = softmax((q * scale) k^T) v   per (b, head), for the FIRST nq query
+ *   rows of every image (nq = T: all tokens; nq = 1: the class token only, which is all the last
+ *   block of an embedding forward needs).
  * K and V of one (b, head) are LDS-resident; QK^T and PV are MFMA 32x32x16
  * tiles; softmax stays in registers.  (HP/src/models_vit.py:69-78;
  * nn.MultiheadAttention inside torchvision EncoderBlock, HP/src/main_backbone.py:554.)
  * Requirements: hd == 64, T <= 288. */
 int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
-                  float scale, void* out, void* stream);
+                  float scale, int32_t nq, void* out, void* stream);
 
 /* Final step of extract_features for the CLS token:
  *   e = ln ? LayerNorm(tok[b][0]) : tok[b][0];  optionally L2-normalised.

@@ -30,7 +30,7 @@ def test_argument_validation_without_gpu(hcir_built):
     # null pointers / bad shapes are rejected before any launch
     assert L.hcir_sim_topk(None, 1, None, 1, 8, 1, 0, None, None, 0, None, None, None, 0, None) == -1
     assert L.hcir_gemm_f16(None, 8, None, 8, None, None, 1, 8, 8, 0, None, 8, None) == -1
-    assert L.hcir_attn_fwd(None, 1, 1, 1, 64, 1.0, None, None) == -1
+    assert L.hcir_attn_fwd(None, 1, 1, 1, 64, 1.0, 1, None, None) == -1
     assert L.hcir_topk_merge(None, None, 1, 1, 1, 1, None, None, None) == -1
 
 

@@ -110,9 +110,24 @@ def test_attention(L, b, t, h):
     ref = ref.permute(0, 2, 1, 3).reshape(b, t, h * hd)
     out = torch.empty(b, t, h * hd, dtype=torch.float16, device="cuda")
     qd = qkv.cuda()
-    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, scale, out.data_ptr(), _st()) == 0
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, scale, t, out.data_ptr(), _st()) == 0
     # P is rounded to fp16 before PV (2^-11 relative per term), output rounded to fp16
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
+
+
+def test_attention_query_row_limit(L):
+    """nq < T: only the first nq query rows are computed, written compactly [B][nq][H*hd]."""
+    b, t, h, hd = 3, 197, 12, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(b, t, 3, h, hd, generator=g).half()
+    qd = qkv.cuda()
+    full = torch.empty(b, t, h * hd, dtype=torch.float16, device="cuda")
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, t, full.data_ptr(), _st()) == 0
+    for nq in (1, 40):
+        part = torch.empty(b, nq, h * hd, dtype=torch.float16, device="cuda")
+        assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, nq, part.data_ptr(), _st()) == 0
+        assert torch.equal(part, full[:, :nq])
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, t + 1, full.data_ptr(), _st()) == -1
 
 
 def test_attention_spiked_row(L):
@@ -125,7 +140,7 @@ def test_attention_spiked_row(L):
     ref = (torch.softmax((q * hd ** -0.5) @ k.transpose(-2, -1), -1) @ v).permute(0, 2, 1, 3).reshape(b, t, hd)
     out = torch.empty(b, t, hd, dtype=torch.float16, device="cuda")
     qd = qkv.cuda()
-    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, out.data_ptr(), _st()) == 0
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, hd ** -0.5, t, out.data_ptr(), _st()) == 0
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
 
 
@@ -214,6 +229,8 @@ def test_vit_b16_embedding_vs_oracle(L, resid, monkeypatch):
     print(f"resid {resid}: embedding 1-cos = {_cos_err(got, ref):.2e}")
     assert _cos_err(got, ref) <= (1e-4 if resid == torch.float16 else 1e-5)   # bar 1e-3; measured far below
     ref_cls, ref_pool = ovit.vitwrapper_forward(sd, x, "backbone.")
+    # extract_features runs the CLS-only last block, backbone(x) the full one: same class token
+    assert _cos_err(got, cls.cpu()) <= 1e-6
     assert _cos_err(cls.cpu(), ref_cls) <= 1e-3
     assert _cos_err(pooled.cpu(), ref_pool) <= 1e-3
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=3e-2 * ref.abs().max().item(), rtol=0)

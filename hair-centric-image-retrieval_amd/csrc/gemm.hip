@@ -22,16 +22,20 @@ using GemmCfg = SimCfg<_Float16, 2, 2, 2>;  // GM = 128 W rows, QB = 128 A rows
 // far below the fp16 rounding of the output): 1 rcp + 1 exp2 + 7 fma instead of erff's ~40
 // instructions — the fc1 epilogue evaluates it 16K times per wave tile.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-  const float erf_abs = __builtin_fmaf(-p * t, e, 1.0f);
-  const float erfv = __builtin_copysignf(erf_abs, x);
-  return 0.5f * x * (1.0f + erfv);
+  // erfc(z) ~ P(t) t exp(-z^2), t = 1/(1 + p z), z = |x|/sqrt2 (A&S 7.1.26);
+  // gelu(x) = x * 0.5 * erfc(-x/sqrt2) = max(x, 0) - |x| * q,  q = 0.5 * erfc(z)  (both signs of x).
+  // Constants folded: w = z * sqrt(log2 e) so that exp(-z^2) = exp2(-w^2); 0.5 folded into P.
+  constexpr float kW = 0.70710678118654752440f * 1.20112240878645f;   // 1/sqrt2 * sqrt(log2 e)
+  constexpr float kP = 0.3275911f / 1.20112240878645f;                // p / sqrt(log2 e)
+  const float w = fabsf(x) * kW;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(kP, w, 1.0f));
+  float p = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-(w * w));
+  const float q = p * t * e;
+  return __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
 }
 
 struct GemmArgs {

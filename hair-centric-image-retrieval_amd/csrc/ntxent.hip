@@ -12,8 +12,9 @@
 //   ntxent_tiles  : sim_core.h tile engine; workgroup (x = column tile of 128, y = row block of
 //                   128); a lane owns one logits ROW and folds its 16 scores per MFMA tile
 //                   into an online (max, sum-of-exp2) pair; diagonal skipped, positive captured.
-//   ntxent_reduce : one workgroup: merges the per-(column tile, wave, half) partials of each
-//                   row in a fixed order (deterministic), writes row_lse and the mean loss.
+//   ntxent_rows   : one thread per row merges the per-column-tile partials in tile order
+//                   (deterministic), writes row_lse and the row's loss term.
+//   ntxent_reduce : one workgroup sums the 2B loss terms in a fixed tree -> mean loss.
 #include "sim_core.h"
 
 namespace {
@@ -40,17 +41,17 @@ __global__ __launch_bounds__(256) void ntxent_prep(const T* __restrict__ z0, con
 
 struct NtArgs {
   const void* zn;
-  float* pm;   // [nct][4][2B] running max (log2 domain)
-  float* pl;   // [nct][4][2B] sum of exp2
-  float* pp;   // [nct][4][2B] positive logit (log2 domain) or -inf
+  float* pm;   // [nct][2B] running max (log2 domain) per column tile
+  float* pl;   // [nct][2B] sum of exp2
+  float* pp;   // [nct][2B] positive logit (log2 domain) or -inf
   int64_t n;   // 2B
   int64_t b;
   int d;
   float scale_log2;  // inv_t * log2(e)
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void ntxent_tiles(NtArgs a) {
+template <typename T, bool GLDS>
+__global__ __launch_bounds__(256, 2) void ntxent_tiles(NtArgs a) {
   using Cfg = SimCfg<T, 2, 2, 2>;  // 128 column rows streamed x 128 logits rows resident
   constexpr int EPS = SimElem<T>::kPerStage;
   __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
@@ -69,17 +70,30 @@ __global__ __launch_bounds__(256) void ntxent_tiles(NtArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
 
-  u32x4 regs[Cfg::NLOAD];
-  sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, 0, tid);
-  sim_stage_store<Cfg>(regs, lds, tid);
-  __syncthreads();
-  for (int kc = 0; kc < nkc; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nkc) sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, kc + 1, tid);
-    sim_stage_mfma<T, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_c, wave_r, lane);
-    if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+  if constexpr (GLDS) {
+    sim_stage_glds<T, Cfg>(lds, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, 0, tid);
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int cur = kc & 1;
+      sim_glds_retire_and_sync();
+      if (kc + 1 < nkc)
+        sim_stage_glds<T, Cfg>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d,
+                               kc + 1, tid);
+      sim_stage_mfma<T, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_c, wave_r, lane);
+    }
+  } else {
+    u32x4 regs[Cfg::NLOAD];
+    sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, 0, tid);
+    sim_stage_store<Cfg>(regs, lds, tid);
     __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int cur = kc & 1;
+      if (kc + 1 < nkc) sim_stage_load<T, Cfg>(regs, zn, c0, a.n - 1, zn, r0, a.n - 1, a.d, kc + 1, tid);
+      sim_stage_mfma<T, Cfg, 2>(acc, lds + cur * Cfg::STAGE_BYTES, wave_c, wave_r, lane);
+      if (kc + 1 < nkc) sim_stage_store<Cfg>(regs, lds + (cur ^ 1) * Cfg::STAGE_BYTES, tid);
+      __syncthreads();
+    }
   }
+  __syncthreads();  // stage buffers are re-used below for the in-workgroup merge
 
   const float ninf = -__builtin_huge_valf();
 #pragma unroll
@@ -109,38 +123,65 @@ __global__ __launch_bounds__(256) void ntxent_tiles(NtArgs a) {
         m = mn;
       }
     }
-    if (row < a.n) {
-      const int src = wave_c * 2 + h;
-      const int64_t o = ((int64_t)blockIdx.x * 4 + src) * a.n + row;
-      a.pm[o] = m;
-      a.pl[o] = l;
-      a.pp[o] = pv;
+    // the four (wave_c, lane-half) partials of a row meet in LDS: [128 rows][4 src][m, l, p]
+    {
+      float* red = reinterpret_cast<float*>(lds);
+      const int rl = wave_r * 64 + rt * 32 + r, src = wave_c * 2 + h;
+      red[(rl * 4 + src) * 3 + 0] = m;
+      red[(rl * 4 + src) * 3 + 1] = l;
+      red[(rl * 4 + src) * 3 + 2] = pv;
     }
   }
-}
-
-__global__ __launch_bounds__(1024) void ntxent_reduce(const float* __restrict__ pm,
-                                                      const float* __restrict__ pl,
-                                                      const float* __restrict__ pp, int64_t n,
-                                                      int nparts, float* __restrict__ loss,
-                                                      float* __restrict__ row_lse) {
-  __shared__ float red[1024];
-  float local = 0.f;
-  for (int64_t row = threadIdx.x; row < n; row += 1024) {
-    float m = -__builtin_huge_valf(), l = 0.f, pv = -__builtin_huge_valf();
-    for (int p = 0; p < nparts; ++p) {
-      const float mp = pm[(int64_t)p * n + row], lp = pl[(int64_t)p * n + row];
-      pv = fmaxf(pv, pp[(int64_t)p * n + row]);
+  __syncthreads();
+  if (tid < 128 && r0 + tid < a.n) {
+    const float* red = reinterpret_cast<const float*>(lds) + tid * 12;
+    float m = ninf, l = 0.f, pv = ninf;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {  // fixed order: deterministic
+      const float mp = red[s * 3], lp = red[s * 3 + 1];
+      pv = fmaxf(pv, red[s * 3 + 2]);
       if (lp > 0.f) {
         const float mn = fmaxf(m, mp);
-        l = l * exp2f(m - mn) + lp * exp2f(mp - mn);
+        l = l * __builtin_amdgcn_exp2f(m - mn) + lp * __builtin_amdgcn_exp2f(mp - mn);
         m = mn;
       }
     }
-    const float lse2 = m + log2f(l);  // log2 domain
-    if (row_lse) row_lse[row] = lse2 * kLn2;
-    local += (lse2 - pv) * kLn2;
+    const int64_t o = (int64_t)blockIdx.x * a.n + r0 + tid;
+    a.pm[o] = m;
+    a.pl[o] = l;
+    a.pp[o] = pv;
   }
+}
+
+// one thread per logits row: merge the per-column-tile partials in tile order, write
+// row_lse and the row's loss term (lse - positive logit)
+__global__ __launch_bounds__(256) void ntxent_rows(const float* __restrict__ pm,
+                                                   const float* __restrict__ pl,
+                                                   const float* __restrict__ pp, int64_t n, int nparts,
+                                                   float* __restrict__ row_loss,
+                                                   float* __restrict__ row_lse) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  float m = -__builtin_huge_valf(), l = 0.f, pv = -__builtin_huge_valf();
+  for (int p = 0; p < nparts; ++p) {
+    const float mp = pm[(int64_t)p * n + row], lp = pl[(int64_t)p * n + row];
+    pv = fmaxf(pv, pp[(int64_t)p * n + row]);
+    if (lp > 0.f) {
+      const float mn = fmaxf(m, mp);
+      l = l * exp2f(m - mn) + lp * exp2f(mp - mn);
+      m = mn;
+    }
+  }
+  const float lse2 = m + log2f(l);  // log2 domain
+  if (row_lse) row_lse[row] = lse2 * kLn2;
+  row_loss[row] = (lse2 - pv) * kLn2;
+}
+
+__global__ __launch_bounds__(1024) void ntxent_reduce(const float* __restrict__ row_loss, int64_t n,
+                                                      float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float local = 0.f;
+  for (int64_t row = threadIdx.x; row < n; row += 1024) local += row_loss[row];  // fixed order
   red[threadIdx.x] = local;
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) {
@@ -152,7 +193,7 @@ __global__ __launch_bounds__(1024) void ntxent_reduce(const float* __restrict__ 
 
 struct NtWorkspace {
   void* zn;
-  float *pm, *pl, *pp;
+  float *pm, *pl, *pp, *row_loss;
   size_t bytes;
 };
 
@@ -168,9 +209,10 @@ NtWorkspace nt_carve(void* base, int64_t b, int d, int dtype) {
   const int64_t n = 2 * b;
   const int64_t nct = hcir_cdiv(n, 128);
   w.zn = take((size_t)n * d * (dtype == HCIR_F32 ? 4 : 2));
-  w.pm = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
-  w.pl = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
-  w.pp = reinterpret_cast<float*>(take((size_t)nct * 4 * n * 4));
+  w.pm = reinterpret_cast<float*>(take((size_t)nct * n * 4));
+  w.pl = reinterpret_cast<float*>(take((size_t)nct * n * 4));
+  w.pp = reinterpret_cast<float*>(take((size_t)nct * n * 4));
+  w.row_loss = reinterpret_cast<float*>(take((size_t)n * 4));
   w.bytes = off;
   return w;
 }
@@ -184,10 +226,15 @@ int nt_run(const void* z0, const void* z1, int64_t b, int d, float inv_t, float*
                      static_cast<const T*>(z0), static_cast<const T*>(z1), b, d, static_cast<T*>(w.zn));
   HCIR_LAUNCH_CHECK();
   NtArgs a{w.zn, w.pm, w.pl, w.pp, n, b, d, inv_t * kLog2e};
-  hipLaunchKernelGGL(ntxent_tiles<T>, dim3(nct, nct), dim3(256), 0, st, a);
+  if (d % SimElem<T>::kPerStage == 0)
+    hipLaunchKernelGGL((ntxent_tiles<T, true>), dim3(nct, nct), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((ntxent_tiles<T, false>), dim3(nct, nct), dim3(256), 0, st, a);
   HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ntxent_reduce, dim3(1), dim3(1024), 0, st, w.pm, w.pl, w.pp, n, nct * 4, loss,
-                     row_lse);
+  hipLaunchKernelGGL(ntxent_rows, dim3((unsigned)hcir_cdiv(n, 256)), dim3(256), 0, st, w.pm, w.pl, w.pp, n,
+                     nct, w.row_loss, row_lse);
+  HCIR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ntxent_reduce, dim3(1), dim3(1024), 0, st, w.row_loss, n, loss);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

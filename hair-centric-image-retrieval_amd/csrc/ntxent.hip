@@ -48,9 +48,12 @@ struct NtArgs {
   int64_t b;
   int d;
   float scale_log2;  // inv_t * log2(e)
+  // backward (BWD = true): W[i][j] = p_ij + p_ji - 2*[j == pos(i)], diagonal 0, fp16 [2B][2B]
+  const float* lse2;  // [2B] row log-sum-exp in the log2 domain
+  _Float16* wmat;
 };
 
-template <typename T, bool GLDS>
+template <typename T, bool GLDS, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void ntxent_tiles(NtArgs a) {
   using Cfg = SimCfg<T, 2, 2, 2>;  // 128 column rows streamed x 128 logits rows resident
   constexpr int EPS = SimElem<T>::kPerStage;
@@ -96,6 +99,38 @@ __global__ __launch_bounds__(256, 2) void ntxent_tiles(NtArgs a) {
   __syncthreads();  // stage buffers are re-used below for the in-workgroup merge
 
   const float ninf = -__builtin_huge_valf();
+  if constexpr (BWD) {
+    // ---- backward tile: the lane owns logits row `row`; its 16 registers per MFMA tile are 4 groups
+    //      of 4 consecutive columns -> 8-byte fp16 stores into W[row][col..col+3]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int64_t row = r0 + wave_r * 64 + rt * 32 + r;
+      if (row >= a.n) continue;
+      const int64_t pos = row < a.b ? row + a.b : row - a.b;
+      const float lrow = a.lse2[row];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          const int64_t col0 = c0 + wave_c * 64 + ct * 32 + 8 * grp + 4 * h;
+          if (col0 >= a.n) continue;  // n is a multiple of 8: a group of 4 is inside or outside
+          const f32x4 lcol = *reinterpret_cast<const f32x4*>(a.lse2 + col0);
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int64_t col = col0 + e;
+            const float x = acc[ct][rt][4 * grp + e] * a.scale_log2;
+            float w = __builtin_amdgcn_exp2f(x - lrow) + __builtin_amdgcn_exp2f(x - lcol[e]);
+            w = (col == pos) ? w - 2.0f : w;
+            w = (col == row) ? 0.f : w;
+            o[e] = (_Float16)w;
+          }
+          *reinterpret_cast<f16x4*>(a.wmat + row * a.n + col0) = o;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int64_t row = r0 + wave_r * 64 + rt * 32 + r;
@@ -191,13 +226,53 @@ __global__ __launch_bounds__(1024) void ntxent_reduce(const float* __restrict__ 
   if (threadIdx.x == 0) *loss = red[0] / (float)n;
 }
 
+// zt[k][i] = zn[i][k] as fp16 (the "weight" operand of dU = W . U on hcir_gemm_f16), and lse -> log2 domain
+template <typename T>
+__global__ void ntxent_bwd_prep(const T* __restrict__ zn, const float* __restrict__ row_lse, int64_t n, int d,
+                                _Float16* __restrict__ zt, float* __restrict__ lse2) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) lse2[t] = row_lse[t] * kLog2e;
+  if (t < n * d) {
+    const int64_t i = t / d;
+    const int k = (int)(t - i * d);
+    zt[(int64_t)k * n + i] = (_Float16)(float)zn[t];
+  }
+}
+
+// dx_i = coef * rn_i * (g_i - (g_i . u_i) u_i), one wave per row; g = W.U (fp32), u = normalised row
+template <typename T>
+__global__ __launch_bounds__(256) void ntxent_bwd_finish(const float* __restrict__ g, const T* __restrict__ zn,
+                                                         const T* __restrict__ z0, const T* __restrict__ z1,
+                                                         int64_t b, int d, float coef, T* __restrict__ dz0,
+                                                         T* __restrict__ dz1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * b) return;
+  const T* x = row < b ? z0 + row * d : z1 + (row - b) * d;
+  T* dx = row < b ? dz0 + row * d : dz1 + (row - b) * d;
+  float ss = 0.f, gu = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float xv = (float)x[k];
+    ss = __builtin_fmaf(xv, xv, ss);
+    gu = __builtin_fmaf(g[row * d + k], (float)zn[row * d + k], gu);
+  }
+  ss = wave_sum(ss);
+  gu = wave_sum(gu);
+  const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  for (int k = lane; k < d; k += 64)
+    dx[k] = (T)(coef * rn * (g[row * d + k] - gu * (float)zn[row * d + k]));
+}
+
 struct NtWorkspace {
   void* zn;
   float *pm, *pl, *pp, *row_loss;
+  // backward only
+  _Float16 *wmat, *zt;
+  float *lse2, *g;
   size_t bytes;
 };
 
-NtWorkspace nt_carve(void* base, int64_t b, int d, int dtype) {
+NtWorkspace nt_carve(void* base, int64_t b, int d, int dtype, bool bwd = false) {
   NtWorkspace w;
   char* c = static_cast<char*>(base);
   size_t off = 0;
@@ -213,6 +288,15 @@ NtWorkspace nt_carve(void* base, int64_t b, int d, int dtype) {
   w.pl = reinterpret_cast<float*>(take((size_t)nct * n * 4));
   w.pp = reinterpret_cast<float*>(take((size_t)nct * n * 4));
   w.row_loss = reinterpret_cast<float*>(take((size_t)n * 4));
+  w.wmat = nullptr;
+  w.zt = nullptr;
+  w.lse2 = w.g = nullptr;
+  if (bwd) {
+    w.wmat = reinterpret_cast<_Float16*>(take((size_t)n * n * 2));
+    w.zt = reinterpret_cast<_Float16*>(take((size_t)n * d * 2));
+    w.lse2 = reinterpret_cast<float*>(take((size_t)n * 4));
+    w.g = reinterpret_cast<float*>(take((size_t)n * d * 4));
+  }
   w.bytes = off;
   return w;
 }
@@ -225,7 +309,7 @@ int nt_run(const void* z0, const void* z1, int64_t b, int d, float inv_t, float*
   hipLaunchKernelGGL(ntxent_prep<T>, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0, st,
                      static_cast<const T*>(z0), static_cast<const T*>(z1), b, d, static_cast<T*>(w.zn));
   HCIR_LAUNCH_CHECK();
-  NtArgs a{w.zn, w.pm, w.pl, w.pp, n, b, d, inv_t * kLog2e};
+  NtArgs a{w.zn, w.pm, w.pl, w.pp, n, b, d, inv_t * kLog2e, nullptr, nullptr};
   if (d % SimElem<T>::kPerStage == 0)
     hipLaunchKernelGGL((ntxent_tiles<T, true>), dim3(nct, nct), dim3(256), 0, st, a);
   else
@@ -239,9 +323,56 @@ int nt_run(const void* z0, const void* z1, int64_t b, int d, float inv_t, float*
   return HCIR_OK;
 }
 
+template <typename T>
+int nt_run_bwd(const void* z0, const void* z1, int64_t b, int d, float inv_t, const float* row_lse,
+               float grad_out, void* dz0, void* dz1, const NtWorkspace& w, hipStream_t st) {
+  const int64_t n = 2 * b;
+  const int nct = (int)hcir_cdiv(n, 128);
+  hipLaunchKernelGGL(ntxent_prep<T>, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0, st,
+                     static_cast<const T*>(z0), static_cast<const T*>(z1), b, d, static_cast<T*>(w.zn));
+  HCIR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ntxent_bwd_prep<T>, dim3((unsigned)hcir_cdiv(n * d, 256)), dim3(256), 0, st,
+                     static_cast<const T*>(w.zn), row_lse, n, d, w.zt, w.lse2);
+  HCIR_LAUNCH_CHECK();
+  NtArgs a{w.zn, w.pm, w.pl, w.pp, n, b, d, inv_t * kLog2e, w.lse2, w.wmat};
+  if (d % SimElem<T>::kPerStage == 0)
+    hipLaunchKernelGGL((ntxent_tiles<T, true, true>), dim3(nct, nct), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((ntxent_tiles<T, false, true>), dim3(nct, nct), dim3(256), 0, st, a);
+  HCIR_LAUNCH_CHECK();
+  // g[2B][D] = W[2B][2B] . U[2B][D]  ==  hcir_gemm_f16(A = W, "weights" = U^T [D][2B])
+  const int rc = hcir_gemm_f16(w.wmat, n, w.zt, n, nullptr, nullptr, n, d, (int32_t)n, HCIR_EPI_BIAS_F32,
+                               w.g, d, st);
+  if (rc != HCIR_OK) return rc;
+  hipLaunchKernelGGL(ntxent_bwd_finish<T>, dim3((unsigned)hcir_cdiv(n, 4)), dim3(256), 0, st, w.g,
+                     static_cast<const T*>(w.zn), static_cast<const T*>(z0), static_cast<const T*>(z1), b, d,
+                     grad_out * inv_t / (float)n, static_cast<T*>(dz0), static_cast<T*>(dz1));
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t hcir_ntxent_bwd_workspace_bytes(int64_t b, int32_t d, int dtype) {
+  if (b <= 0 || d <= 0) return 0;
+  return nt_carve(nullptr, b, d, dtype, true).bytes;
+}
+
+int hcir_ntxent_bwd(const void* z0, const void* z1, int64_t b, int32_t d, int dtype, float inv_t,
+                    const float* row_lse, float grad_out, void* dz0, void* dz1, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  HCIR_ENTER();
+  if (!z0 || !z1 || !row_lse || !dz0 || !dz1 || b <= 0 || d <= 0 || (d & 7) || (b & 3)) return HCIR_ERR_INVALID;
+  if (dtype != HCIR_F32 && dtype != HCIR_F16 && dtype != HCIR_BF16) return HCIR_ERR_UNSUPPORTED;
+  const NtWorkspace w = nt_carve(workspace, b, d, dtype, true);
+  if (!workspace || workspace_bytes < w.bytes) return HCIR_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == HCIR_F32) return nt_run_bwd<float>(z0, z1, b, d, inv_t, row_lse, grad_out, dz0, dz1, w, st);
+  if (dtype == HCIR_F16) return nt_run_bwd<_Float16>(z0, z1, b, d, inv_t, row_lse, grad_out, dz0, dz1, w, st);
+  return nt_run_bwd<__bf16>(z0, z1, b, d, inv_t, row_lse, grad_out, dz0, dz1, w, st);
+}
 
 size_t hcir_ntxent_workspace_bytes(int64_t b, int32_t d, int dtype) {
   if (b <= 0 || d <= 0) return 0;

@@ -42,6 +42,8 @@ SIGNATURES = {
     "hcir_topk_merge": (c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "hcir_ntxent_workspace_bytes": (c_sz, [c_i64, c_i32, c_int]),
     "hcir_ntxent_fwd": (c_int, [c_vp, c_vp, c_i64, c_i32, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_ntxent_bwd_workspace_bytes": (c_sz, [c_i64, c_i32, c_int]),
+    "hcir_ntxent_bwd": (c_int, [c_vp, c_vp, c_i64, c_i32, c_int, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "hcir_layernorm_f16": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
     "hcir_gemm_f16": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,
                               c_vp, c_i64, c_vp]),

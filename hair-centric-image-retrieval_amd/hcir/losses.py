@@ -1,9 +1,8 @@
 """hcir.losses — NTXentLoss with lightly's constructor/forward signature
 (lightly.loss.NTXentLoss; call sites HP/src/pretrain_engine.py:93,725), computed by
-hcir_ntxent_fwd (fused normalise + 2B x 2B MFMA cosine + masked log-sum-exp).
-
-Forward only this round: the value is returned as a detached 0-d device tensor;
-asking for gradients raises NotImplementedError.
+hcir_ntxent_fwd (fused normalise + 2B x 2B MFMA cosine + masked log-sum-exp) and, when the inputs
+require grad, differentiated by hcir_ntxent_bwd through a torch.autograd.Function — a drop-in
+`criterion(out0, out1)` for a training loop whose backbone runs on PyTorch-ROCm.
 """
 from __future__ import annotations
 
@@ -35,6 +34,34 @@ def ntxent_forward(out0: torch.Tensor, out1: torch.Tensor, temperature: float, w
     return (loss, lse) if want_lse else loss
 
 
+def ntxent_backward(out0, out1, temperature, lse, grad_out: float):
+    b, d = out0.shape
+    L = _lib.lib()
+    dt = _DT[out0.dtype]
+    ws = _ws.get(out0.device, L.hcir_ntxent_bwd_workspace_bytes(b, d, dt))
+    g0, g1 = torch.empty_like(out0), torch.empty_like(out1)
+    check(L.hcir_ntxent_bwd(out0.data_ptr(), out1.data_ptr(), b, d, dt, 1.0 / temperature, lse.data_ptr(),
+                            float(grad_out), g0.data_ptr(), g1.data_ptr(), ws.data_ptr(), ws.numel(),
+                            _stream(out0)), "hcir_ntxent_bwd")
+    return g0, g1
+
+
+class _NTXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out0, out1, temperature):
+        out0, out1 = out0.contiguous(), out1.contiguous()
+        loss, lse = ntxent_forward(out0, out1, temperature, want_lse=True)
+        ctx.save_for_backward(out0, out1, lse)
+        ctx.temperature = temperature
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        out0, out1, lse = ctx.saved_tensors
+        g0, g1 = ntxent_backward(out0, out1, ctx.temperature, lse, float(grad))  # one host read of dL
+        return g0, g1, None
+
+
 class NTXentLoss(nn.Module):
     """NTXentLoss(temperature=0.5, memory_bank_size=0, gather_distributed=False)."""
 
@@ -52,5 +79,7 @@ class NTXentLoss(nn.Module):
 
     def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and (out0.requires_grad or out1.requires_grad):
-            raise NotImplementedError("hcir_ntxent is forward-only this round; call under torch.no_grad()")
+            if out0.shape[0] % 4:
+                raise HcirError("hcir_ntxent_bwd needs a batch size that is a multiple of 4")
+            return _NTXentFn.apply(out0, out1, self.temperature)
         return ntxent_forward(out0.contiguous(), out1.contiguous(), self.temperature)

@@ -127,6 +127,16 @@ int hcir_ntxent_fwd(const void* z0, const void* z1, int64_t b, int32_t d, int dt
                     float inv_t, float* loss, float* row_lse, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* NT-Xent backward: dL/dz0, dL/dz1 (same dtype as the inputs) for the loss of hcir_ntxent_fwd.
+ *   G = (P - Y)/2B,  dU = (1/T)(G + G^T) U,  dz_i = grad_out * (dU_i - (dU_i.u_i) u_i) / ||z_i||
+ * W = P + P^T - 2Y is written once as fp16 [2B][2B] into the workspace and dU = W.U runs on
+ * hcir_gemm_f16 (fp16 MFMA: gradients carry fp16-level relative error for every input dtype).
+ * row_lse: the [2B] vector saved by hcir_ntxent_fwd.  Requirements: d % 8 == 0, b % 4 == 0. */
+size_t hcir_ntxent_bwd_workspace_bytes(int64_t b, int32_t d, int dtype);
+int hcir_ntxent_bwd(const void* z0, const void* z1, int64_t b, int32_t d, int dtype, float inv_t,
+                    const float* row_lse, float grad_out, void* dz0, void* dz1, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ *
  * ViT building blocks (fp16 MFMA, fp32 accumulate, fp32 residual stream).
  * ------------------------------------------------------------------ */

@@ -55,12 +55,35 @@ def test_ntxent_config_c3(dtype, tol, b, d, t):
 
 
 def test_ntxent_errors():
+    from hcir import HcirError
     from hcir.losses import NTXentLoss
-    z = torch.randn(8, 16, device="cuda", requires_grad=True)
-    with pytest.raises(NotImplementedError):
+    z = torch.randn(6, 16, device="cuda", requires_grad=True)   # batch not a multiple of 4
+    with pytest.raises(HcirError):
         NTXentLoss(0.5)(z, z)
     with pytest.raises(ValueError):
         NTXentLoss(1e-9)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-3), (torch.float16, 6e-3)])
+@pytest.mark.parametrize("b,d,t", [(1024, 512, 0.5), (64, 128, 0.07), (36, 72, 0.7)])
+def test_ntxent_backward_vs_autograd(dtype, tol, b, d, t):
+    """dL/dz0, dL/dz1 of hcir_ntxent_bwd vs torch autograd through the fp64 restatement of the reference's
+    loss.  The backward's second product (dU = W.U) runs in fp16 MFMA: tolerance is relative to max|grad|."""
+    from hcir.losses import NTXentLoss
+    g = torch.Generator().manual_seed(b + d)
+    z0, z1 = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g)
+    a0 = z0.to(dtype).float().double().requires_grad_(True)   # the values the kernel actually sees
+    a1 = z1.to(dtype).float().double().requires_grad_(True)
+    (ont.ntxent_dualview(a0, a1, t) * 3.0).backward()
+    x0 = z0.cuda().to(dtype).requires_grad_(True)
+    x1 = z1.cuda().to(dtype).requires_grad_(True)
+    loss = NTXentLoss(t)(x0, x1)
+    assert loss.requires_grad
+    (loss * 3.0).backward()
+    for got, ref in ((x0.grad, a0.grad), (x1.grad, a1.grad)):
+        assert got.dtype == dtype and got.shape == ref.shape
+        scale = ref.abs().max().item()
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref.float().numpy(), atol=tol * scale, rtol=0)
 
 
 # ------------------------------------------------------------------ backbones

@@ -465,16 +465,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       if (row < 256) {
         int nr = n0 + row;
         nr = nr > g.n - 1 ? g.n - 1 : nr;
-        src[i] = g.w + (int64_t)nr * g.k + chunk * 8;
+        src[i] = g.w + (int64_t)nr * g.ldw + chunk * 8;
       } else {
         int64_t mr = m0 + (row - 256);
         mr = mr > g.m - 1 ? g.m - 1 : mr;
-        src[i] = g.a + mr * (int64_t)g.k + chunk * 8;
+        src[i] = g.a + mr * g.lda + chunk * 8;
       }
     }
   };
   int issue_ti = 0, issue_kc = 0;  // next stage to issue
   auto issue_piece = [&](int slot, int i) {
+    // default cache policy on both operands: `nt` (aux 2) on the activation rows measured +-1 %,
+    // on the W rows -9..-13 % (every CU of an XCD re-reads them from L2)
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(src[i] + issue_kc * 64),
         (__attribute__((address_space(3))) void*)(lds + slot * G256::STAGE_BYTES +
@@ -750,7 +752,10 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
                   int64_t ldo, void* stream) {
   HCIR_ENTER();
   if (!a || !w || !out || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
-  if ((k & 7) || (n & 7) || lda != k || ldw != k || ldo < n || (ldo & 3)) return HCIR_ERR_INVALID;
+  if ((k & 7) || (n & 7) || lda < k || ldw < k || (lda & 7) || (ldw & 7) || ldo < n || (ldo & 3))
+    return HCIR_ERR_INVALID;
+  // row pitches other than k: only the 256x256 persistent kernel carries separate pitches
+  if ((lda != k || ldw != k) && !(k % 64 == 0 && m >= 1024 && n % 256 == 0)) return HCIR_ERR_UNSUPPORTED;
   if ((epilogue == HCIR_EPI_AFFINE_RELU_F16 || epilogue == HCIR_EPI_AFFINE_F32) && !scale)
     return HCIR_ERR_INVALID;
   if (hcir_cdiv(m, 128) * hcir_cdiv(n, 128) > 0x7fffffff) return HCIR_ERR_INVALID;

@@ -165,7 +165,9 @@ typedef enum {
  * nn.Linear weight as stored).  Replaces nn.Linear / MultiheadAttention
  * in_proj / out_proj / MLPBlock / timm Mlp  (HP/src/models_vit.py:63,66,70,79;
  * HP/src/main_backbone.py:554 -> torchvision EncoderBlock).
- * Requirements: K % 8 == 0, N % 8 == 0; bias may be NULL. */
+ * Requirements: K % 8 == 0, N % 8 == 0; bias may be NULL.  lda / ldw are row pitches in
+ * elements (>= K, multiples of 8); pitches other than K are carried by the persistent
+ * 256 x 256 kernel only (M >= 1024, N % 256 == 0, K % 64 == 0), else HCIR_ERR_UNSUPPORTED. */
 int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
                   const float* bias, const float* scale, int64_t m, int32_t n,
                   int32_t k, int epilogue, void* out, int64_t ldo, void* stream);

@@ -27,8 +27,12 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+# m >= 1024 with n % 256 == 0 and k % 64 == 0 takes the persistent 256 x 256 kernel (full and edge tiles,
+# one tile per workgroup and several), everything else the 128 x 128 kernel
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (197 * 3, 768, 768), (1000, 2304, 768),
-                                   (333, 3072, 768), (260, 768, 3072), (5, 8, 8), (130, 136, 72)])
+                                   (333, 3072, 768), (260, 768, 3072), (5, 8, 8), (130, 136, 72),
+                                   (1024, 256, 64), (1300, 768, 768), (197 * 11, 2304, 768),
+                                   (1537, 3072, 768), (1100, 768, 3072), (256 * 70 + 3, 1024, 128)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 6])
 def test_gemm_epilogues(L, m, n, k, epi):
     from hcir import _lib
@@ -64,6 +68,32 @@ def test_gemm_epilogues(L, m, n, k, epi):
     # fp32 accumulate of exact fp16 products: error is fp32 summation + (for fp16 outputs) one rounding
     tol = 2e-3 if epi in (0, 1, 6) else 1e-4
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=tol * max(1.0, ref.abs().max().item()), rtol=0)
+
+
+@pytest.mark.parametrize("epi", [0, 6])
+def test_gemm_row_pitch(L, epi):
+    """A and W as strided views (row pitch > k): the persistent kernel carries separate pitches; the small
+    kernel refuses them."""
+    g = torch.Generator().manual_seed(91 + epi)
+    m, n, k, lda, ldw, ldo = 1500, 512, 192, 256, 320, 640
+    abuf = (torch.randn(m, lda, generator=g) * 0.5).half()
+    wbuf = (torch.randn(n, ldw, generator=g) * k ** -0.5).half()
+    bias = torch.randn(n, generator=g)
+    obuf = torch.randn(m, ldo, generator=g).half()
+    ref = abuf[:, :k].float() @ wbuf[:, :k].float().t() + bias
+    if epi == 6:
+        ref = obuf[:, :n].float() + ref
+    ad, wd, bd, od = abuf.cuda(), wbuf.cuda(), bias.cuda(), obuf.cuda()
+    assert L.hcir_gemm_f16(ad.data_ptr(), lda, wd.data_ptr(), ldw, bd.data_ptr(), None, m, n, k, epi,
+                           od.data_ptr(), ldo, _st()) == 0
+    got = od.float().cpu()
+    np.testing.assert_allclose(got[:, :n].numpy(), ref.numpy(), atol=2e-3 * ref.abs().max().item(), rtol=0)
+    np.testing.assert_array_equal(got[:, n:].numpy(), obuf[:, n:].float().numpy())   # padding untouched
+    # small kernel (m < 1024): pitches other than k are refused, not mis-read
+    assert L.hcir_gemm_f16(ad.data_ptr(), lda, wd.data_ptr(), ldw, bd.data_ptr(), None, 512, n, k, epi,
+                           od.data_ptr(), ldo, _st()) == -2
+    assert L.hcir_gemm_f16(ad.data_ptr(), k - 8, wd.data_ptr(), ldw, bd.data_ptr(), None, m, n, k, epi,
+                           od.data_ptr(), ldo, _st()) == -1
 
 
 def test_gemm_affine_epilogues(L):
@@ -240,6 +270,25 @@ def test_vit_b16_embedding_vs_oracle(L, resid, monkeypatch):
     ref_m = ovit.projection_head_forward(sd, ovit.vitwrapper_forward(sd, x, "backbone_momentum.")[0],
                                          "projection_head_momentum.")
     assert _cos_err(zm, ref_m) <= 1e-3
+
+
+def test_vit_b16_batch_on_persistent_gemm(L):
+    """Batch 8 (M = 1576 token rows) runs the encoder GEMMs on the persistent 256 x 256 kernel, the path
+    bench.py measures; same 1e-3 cosine bar against the fp32 oracle, per-image results independent of batch."""
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(43)
+    model = SHAM2("vit_b_16").eval()
+    _randomize(model, 2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(11))
+    ref = ovit.sham2_extract_features(sd, x, "vit_b_16")
+    model = model.cuda()
+    with torch.no_grad():
+        got = model.extract_features(x.cuda()).cpu()
+        small = model.extract_features(x[:3].cuda()).cpu()      # 128 x 128 kernel
+    print(f"batch 8: embedding 1-cos = {_cos_err(got, ref):.2e}")
+    assert _cos_err(got, ref) <= 1e-4
+    assert _cos_err(got[:3], small) <= 1e-6
 
 
 def test_vit_requires_no_grad_and_device(L):

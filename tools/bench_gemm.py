@@ -26,7 +26,12 @@ def run(L, m, n, k, epi, iters=20):
     return ms
 
 if __name__ == "__main__":
+    # HCIR_LIBVAR=<tag> loads tools/_libhcir_<tag>.so instead (ablation builds of the same sources)
+    if os.environ.get("HCIR_LIBVAR"):
+        _lib.LIB_PATH = os.path.join(ROOT, "tools", "_libhcir_%s.so" % os.environ["HCIR_LIBVAR"])
     L = _lib.lib()
+    # the first ~50 launches of a process run 10-17 % slower (clock ramp): warm up before timing
+    run(L, 220 * 197, 2304, 768, 0, iters=100)
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     m = b * 197
     tot = 0

@@ -38,6 +38,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
 }
 
+// Internal epilogue codes of hcir_gemm_f16_fused (persistent kernel only), beyond hcir_epilogue:
+//   EPI_RESID_F16_STATS: BIAS_RESID_F16 that also writes per-row partial (sum, sum of squares) of the stored
+//                        fp16 rows, one slice per 64 output features, for the LayerNorm that reads them next;
+//   EPI_LN_BIAS_F16 / EPI_LN_BIAS_GELU_F16: the A rows are the RAW residual rows x and W carries the
+//                        LayerNorm gamma (W' = gamma o W): out = act(rstd[m] (acc - mean[m] c1[n]) + bias[n])
+//                        with c1[n] = sum_k W'[n][k], bias[n] = sum_k beta[k] W[n][k] + b[n]  (LayerNorm folded
+//                        into the GEMM; no normalised copy of the tokens is ever written).
+constexpr int EPI_RESID_F16_STATS = 7;
+constexpr int EPI_LN_BIAS_F16 = 8;
+constexpr int EPI_LN_BIAS_GELU_F16 = 9;
+
 struct GemmArgs {
   const _Float16* a;
   const _Float16* w;
@@ -46,6 +57,9 @@ struct GemmArgs {
   void* out;
   int64_t m, lda, ldw, ldo;
   int n, k;
+  const float* ln_stats;  // [m][2] (mean, rstd) of the A rows           (EPI_LN_*)
+  const float* ln_c1;     // [n]                                           (EPI_LN_*)
+  float* stats_part;      // [n/64][m][2] partial (sum, sumsq) of out rows (EPI_RESID_F16_STATS)
 };
 
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8
@@ -172,13 +186,24 @@ struct WaveAcc<true> {
   }
 };
 
+// 8-lane (one 128-B output line) sum by DPP: quad xor 1, quad xor 2, then the mirror of the 8-lane half row
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
 template <int EPI, bool FULL, bool MF16>
 __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, const WaveAcc<MF16>& acc,
                                                           char* region, int64_t m0w, int nbase,
                                                           int lane) {
   const int r = lane & 31, h = lane >> 5;
-  constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 ||
-                         EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_BIAS_RESID_F16);
+  constexpr bool kLn = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  constexpr bool kGelu = (EPI == HCIR_EPI_BIAS_GELU_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  constexpr bool kResidH = (EPI == HCIR_EPI_BIAS_RESID_F16 || EPI == EPI_RESID_F16_STATS);
+  constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || kGelu || kLn ||
+                         EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH);
   constexpr bool kAffine = (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32);
   constexpr int NPASS = kF16 ? 2 : 4;  // 64 or 32 output features (128 B) per pass
   constexpr int NB = kF16 ? 2 : 1;     // float4 of bias per lane per pass
@@ -194,11 +219,46 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
       bias[pass][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       scale[pass][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
       if (g.bias) bias[pass][j] = *reinterpret_cast<const f32x4*>(g.bias + n);
-      if (kAffine || ((EPI == HCIR_EPI_BIAS_RESID_F32 || EPI == HCIR_EPI_BIAS_RESID_F16) && g.scale))
+      if (kAffine || ((EPI == HCIR_EPI_BIAS_RESID_F32 || kResidH) && g.scale))
         scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
     }
   }
+  // LayerNorm fold, out = rstd[m] acc + (-rstd[m] mean[m]) c1[n] + bias[n]:
+  //   accumulator side: acc * rstd of the 4 (2) rows this lane owns there, before the fp16 image;
+  //   row side: the rank-1 term u[row] * c1[n] with u = -rstd * mean of the 8 rows this lane stores.
+  float ln_rstd[4], ln_u[8];
+  f32x4 c1r[NPASS][NB];
+  if constexpr (kLn) {
+#pragma unroll
+    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) {
+      int64_t mm = m0w + (MF16 ? 16 * mt + (lane & 15) : 32 * mt + r);
+      mm = mm < g.m ? mm : g.m - 1;
+      ln_rstd[mt] = g.ln_stats[2 * mm + 1];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      int64_t mm = m0w + it * 8 + rrow;
+      mm = mm < g.m ? mm : g.m - 1;
+      const f32x2 ms = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * mm);
+      ln_u[it] = -ms[0] * ms[1];
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        c1r[pass][j] = *reinterpret_cast<const f32x4*>(g.ln_c1 + nbase + pass * 64 + rchunk * 8 + 4 * j);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (kLn) {
+#pragma unroll
+    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) asm volatile("" : "+v"(ln_rstd[mt]));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(ln_u[it]));
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) launder(c1r[pass][j]);
+  }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
@@ -221,8 +281,13 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
               f16x4 o;
+              if constexpr (kLn) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)(ln_rstd[mt] * acc.a[nt][mt][4 * grp + e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
+              }
               const int chunk = q * 4 + grp;
               *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
             }
@@ -248,8 +313,13 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           for (int q = 0; q < 4; ++q) {   // 64 features per pass = 4 n-tiles of 16
             const int nt = 4 * pass + q;
             f16x4 o;
+            if constexpr (kLn) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)(ln_rstd[mt] * acc.a[nt][mt][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+            }
             const int chunk = 2 * q + (q16 >> 1);
             *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
           }
@@ -270,7 +340,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
       for (int it0 = 0; it0 < 8; it0 += 4) {
         // fp16 residual: the four old rows of a group are requested back to back (counted waits)
         f16x8 oldh[4];
-        if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
+        if constexpr (kResidH) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int64_t mm = m0w + (it0 + u) * 8 + rrow;
@@ -291,16 +361,33 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
             const float bb = bias[pass][e >> 2][e & 3];
             if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
               x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
-            } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
+            } else if constexpr (kResidH) {
               x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
             } else {
               x += bb;
-              if constexpr (EPI == HCIR_EPI_BIAS_GELU_F16) x = gelu_erf(x);
+              if constexpr (kLn) x = __builtin_fmaf(ln_u[it0 + u], c1r[pass][e >> 2][e & 3], x);
+              if constexpr (kGelu) x = gelu_erf(x);
             }
             o[e] = (_Float16)x;
           }
           const int64_t m = m0w + row;
           if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+          if constexpr (EPI == EPI_RESID_F16_STATS) {
+            // (sum, sum of squares) of the 64 STORED fp16 values of this row slice, for the next LayerNorm
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xv = (float)o[e];
+              s1 += xv;
+              s2 = __builtin_fmaf(xv, xv, s2);
+            }
+            s1 = sum8_dpp(s1);
+            s2 = sum8_dpp(s2);
+            if (rchunk == 0 && (FULL || m < g.m)) {
+              const int64_t slice = (nbase >> 6) + pass;
+              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){s1, s2};
+            }
+          }
         }
       }
     } else {
@@ -437,6 +524,7 @@ struct G256 {
 template <int EPI, bool MF16>
 __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int tiles_n, int tiles_m) {
   __shared__ __attribute__((aligned(16))) char lds[2 * G256::STAGE_BYTES];
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_n = wave >> 2, wave_m = wave & 3;
   const int r = lane & 31, h = lane >> 5;
@@ -452,33 +540,39 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     m0 = (int64_t)(t / tiles_n) * 256;
   };
 
-  // per-thread DMA source pointers of the tile being issued (row base + swizzled chunk)
-  const _Float16* src[G256::NLOAD];
-  auto set_sources = [&](int ti) {
+  // per-thread DMA source offsets of the tile being issued (row + swizzled chunk), in bytes from the
+  // tile's W / activation origin: 32-bit VGPR offsets on wave-uniform 64-bit bases (global saddr mode)
+  uint32_t soff[G256::NLOAD];
+  const char* wbase = nullptr;
+  const char* abase = nullptr;
+  auto set_sources = [&](int t_i) {
     int n0;
     int64_t m0;
-    tile_origin(ti, n0, m0);
+    tile_origin(t_i, n0, m0);
+    wbase = reinterpret_cast<const char*>(g.w + (int64_t)n0 * g.ldw);
+    abase = reinterpret_cast<const char*>(g.a + m0 * g.lda);
 #pragma unroll
     for (int i = 0; i < G256::NLOAD; ++i) {
       const int piece = tid + G256::NT * i;
       const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
       if (row < 256) {
-        int nr = n0 + row;
-        nr = nr > g.n - 1 ? g.n - 1 : nr;
-        src[i] = g.w + (int64_t)nr * g.ldw + chunk * 8;
+        const int nr = n0 + row > g.n - 1 ? g.n - 1 - n0 : row;
+        soff[i] = (uint32_t)(((int64_t)nr * g.ldw + chunk * 8) * 2);
       } else {
-        int64_t mr = m0 + (row - 256);
-        mr = mr > g.m - 1 ? g.m - 1 : mr;
-        src[i] = g.a + mr * g.lda + chunk * 8;
+        int64_t mr = row - 256;
+        mr = m0 + mr > g.m - 1 ? g.m - 1 - m0 : mr;
+        soff[i] = (uint32_t)((mr * g.lda + chunk * 8) * 2);
       }
     }
   };
   int issue_ti = 0, issue_kc = 0;  // next stage to issue
   auto issue_piece = [&](int slot, int i) {
-    // default cache policy on both operands: `nt` (aux 2) on the activation rows measured +-1 %,
-    // on the W rows -9..-13 % (every CU of an XCD re-reads them from L2)
+    // pieces 0..3 are W rows, 4..7 activation rows (i is a constant after unrolling).  Default cache policy
+    // on both operands: `nt` (aux 2) on the activation rows measured +-1 %, on the W rows -9..-13 %
+    // (every CU of an XCD re-reads them from L2)
+    const char* sp = (i < 4 ? wbase : abase) + issue_kc * 128 + soff[i];
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src[i] + issue_kc * 64),
+        (const __attribute__((address_space(1))) void*)sp,
         (__attribute__((address_space(3))) void*)(lds + slot * G256::STAGE_BYTES +
                                                    ((tid & ~63) + G256::NT * i) * 16),
         16, 0, 0);
@@ -722,16 +816,39 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
   tok[bi * t * (int64_t)d + n] = (TokT)(cls[n] + pos_mult * pos[n]);
 }
 
+inline bool gemm_takes_big(int64_t m, int n, int k) { return k % 64 == 0 && m >= 1024 && n % 256 == 0; }
+
+template <int EPI>
+void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
+  const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
+  const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
+  static const bool mf16 = [] { const char* e = getenv("HCIR_GEMM_MFMA"); return !(e && e[0] == '3'); }();
+  if (mf16)
+    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+  else
+    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+}
+
+// (sum, sumsq) slices of hcir_gemm_f16_fused -> (mean, rstd) per row; slices are added in index order
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, int64_t m, float inv_n,
+                                         float eps, float* __restrict__ stats) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = 0; p < parts; ++p) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(part + ((int64_t)p * m + row) * 2);
+    s1 += v[0];
+    s2 += v[1];
+  }
+  const float mean = s1 * inv_n;
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_n), 0.f);
+  *reinterpret_cast<f32x2*>(stats + 2 * row) = (f32x2){mean, 1.0f / sqrtf(var + eps)};
+}
+
 template <int EPI>
 void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  if (g.k % 64 == 0 && g.m >= 1024 && g.n % 256 == 0) {
-    const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
-    const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
-    static const bool mf16 = [] { const char* e = getenv("HCIR_GEMM_MFMA"); return !(e && e[0] == '3'); }();
-    if (mf16)
-      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
-    else
-      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+  if (gemm_takes_big(g.m, g.n, g.k)) {
+    launch_gemm_big<EPI>(g, st);
     return;
   }
   const int tiles_n = (int)hcir_cdiv(g.n, 128), tiles_m = (int)hcir_cdiv(g.m, 128);
@@ -760,7 +877,7 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
     return HCIR_ERR_INVALID;
   if (hcir_cdiv(m, 128) * hcir_cdiv(n, 128) > 0x7fffffff) return HCIR_ERR_INVALID;
   GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
-             lda, ldw, ldo, n, k};
+             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (epilogue) {
     case HCIR_EPI_BIAS_F16: launch_gemm<HCIR_EPI_BIAS_F16>(g, st); break;
@@ -772,6 +889,46 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
     case HCIR_EPI_BIAS_RESID_F16: launch_gemm<HCIR_EPI_BIAS_RESID_F16>(g, st); break;
     default: return HCIR_ERR_UNSUPPORTED;
   }
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_gemm_fused_supported(int64_t m, int32_t n, int32_t k) { return gemm_takes_big(m, n, k) ? 1 : 0; }
+
+int32_t hcir_gemm_stats_slices(int32_t n) { return n / 64; }
+
+int hcir_gemm_f16_fused(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                        const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, void* out,
+                        int64_t ldo, const float* ln_stats, const float* ln_c1, float* stats_part,
+                        void* stream) {
+  HCIR_ENTER();
+  if (!a || !w || !out || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
+  if ((k & 7) || (n & 7) || lda < k || ldw < k || (lda & 7) || (ldw & 7) || ldo < n || (ldo & 7))
+    return HCIR_ERR_INVALID;
+  const bool ln = ln_stats || ln_c1;
+  if (ln && (!ln_stats || !ln_c1 || !bias)) return HCIR_ERR_INVALID;
+  if (ln && stats_part) return HCIR_ERR_INVALID;
+  if (!ln && !stats_part) return HCIR_ERR_INVALID;  // nothing fused: use hcir_gemm_f16
+  if (ln && epilogue != HCIR_EPI_BIAS_F16 && epilogue != HCIR_EPI_BIAS_GELU_F16) return HCIR_ERR_UNSUPPORTED;
+  if (stats_part && epilogue != HCIR_EPI_BIAS_RESID_F16) return HCIR_ERR_UNSUPPORTED;
+  if (!gemm_takes_big(m, n, k)) return HCIR_ERR_UNSUPPORTED;
+  GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
+             lda, ldw, ldo, n, k, ln_stats, ln_c1, stats_part};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats_part) launch_gemm_big<EPI_RESID_F16_STATS>(g, st);
+  else if (epilogue == HCIR_EPI_BIAS_F16) launch_gemm_big<EPI_LN_BIAS_F16>(g, st);
+  else launch_gemm_big<EPI_LN_BIAS_GELU_F16>(g, st);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_ln_stats_finalize(const float* stats_part, int32_t slices, int64_t m, int32_t n_features, float eps,
+                           float* ln_stats, void* stream) {
+  HCIR_ENTER();
+  if (!stats_part || !ln_stats || slices <= 0 || m <= 0 || n_features <= 0) return HCIR_ERR_INVALID;
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)hcir_cdiv(m, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), stats_part, slices, m, 1.0f / (float)n_features, eps,
+                     ln_stats);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

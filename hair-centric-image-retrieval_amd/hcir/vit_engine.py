@@ -24,6 +24,9 @@ from ._lib import HcirError, check
 import os as _os
 
 DEFAULT_RESID_DTYPE = torch.float16 if _os.environ.get("HCIR_RESID", "f32") == "f16" else torch.float32
+# LayerNorm folded into the neighbouring GEMMs (fp16 residual stream, persistent-kernel shapes only);
+# HCIR_LN_FUSE=0 keeps the separate hcir_layernorm_f16 launches
+LN_FUSE = _os.environ.get("HCIR_LN_FUSE", "1") != "0"
 
 
 @dataclass
@@ -78,6 +81,22 @@ class _DevLayer:
         self.proj_b, self.fc1_b, self.fc2_b = _f32(l.proj_b, dev), _f32(l.fc1_b, dev), _f32(l.fc2_b, dev)
         self.ls1 = None if l.ls1 is None else _f32(l.ls1, dev)
         self.ls2 = None if l.ls2 is None else _f32(l.ls2, dev)
+        # LayerNorm fold (hcir_gemm_f16_fused): W' = fp16(gamma o W), c1 = row sums of the ROUNDED W',
+        # bias' = W . beta + b.  LN(x) W^T + b == rstd (x W'^T - mean c1) + bias'
+        self.qkv_wg, self.qkv_c1, self.qkv_c2 = self._fold(l.qkv_w, l.ln1_w, l.ln1_b, l.qkv_b, dev)
+        self.fc1_wg, self.fc1_c1, self.fc1_c2 = self._fold(l.fc1_w, l.ln2_w, l.ln2_b, l.fc1_b, dev)
+
+    @staticmethod
+    def _fold(w, gamma, beta, bias, dev):
+        w64 = w.detach().to(device=dev, dtype=torch.float64)
+        g64 = gamma.detach().to(device=dev, dtype=torch.float64)
+        b64 = beta.detach().to(device=dev, dtype=torch.float64)
+        wg = (w64 * g64[None, :]).to(torch.float16).contiguous()
+        c1 = wg.to(torch.float64).sum(1).to(torch.float32).contiguous()
+        c2 = w64 @ b64
+        if bias is not None:
+            c2 = c2 + bias.detach().to(device=dev, dtype=torch.float64)
+        return wg, c1, c2.to(torch.float32).contiguous()
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -139,6 +158,9 @@ class VitEngine:
                 att_c=torch.empty((b, d), dtype=torch.float16, device=dev),
                 ln_c=torch.empty((b, d), dtype=torch.float16, device=dev),
                 hid_c=torch.empty((b, self.mlp), dtype=torch.float16, device=dev),
+                # LayerNorm fold: partial (sum, sumsq) slices of the residual rows and their (mean, rstd)
+                stats_part=torch.empty((max(d // 64, 1), m, 2), dtype=torch.float32, device=dev),
+                stats=torch.empty((m, 2), dtype=torch.float32, device=dev),
             )
             self._bufs = {key: bufs}  # keep one shape resident
         return bufs
@@ -175,31 +197,63 @@ class VitEngine:
         self._mark("patch_embed")
         scale = (d // self.heads) ** -0.5
         last = len(self.layers) - 1
+        # LayerNorm fold: fp16 residual stream and every GEMM of the block on the persistent kernel
+        fuse = (LN_FUSE and self.resid_dtype == torch.float16
+                and L.hcir_gemm_fused_supported(m, 3 * d, d) and L.hcir_gemm_fused_supported(m, d, d)
+                and L.hcir_gemm_fused_supported(m, self.mlp, d) and L.hcir_gemm_fused_supported(m, d, self.mlp))
+        sp, stats = w["stats_part"], w["stats"]
+        nsl = d // 64
+        have_stats = False  # `stats` holds (mean, rstd) of the current residual rows
+
+        def resid_gemm(a, k, wt, bias, ls, want_stats, what):
+            if want_stats:
+                check(L.hcir_gemm_f16_fused(a.data_ptr(), k, wt.data_ptr(), k, bias.data_ptr(), _p(ls), m, d, k,
+                                            _lib.EPI_BIAS_RESID_F16, tok.data_ptr(), d, None, None, sp.data_ptr(),
+                                            st), what)
+                check(L.hcir_ln_stats_finalize(sp.data_ptr(), nsl, m, d, self.eps, stats.data_ptr(), st),
+                      "hcir_ln_stats_finalize")
+            else:
+                check(L.hcir_gemm_f16(a.data_ptr(), k, wt.data_ptr(), k, bias.data_ptr(), _p(ls), m, d, k,
+                                      self._resid_epi, tok.data_ptr(), d, st), what)
+
         for li, l in enumerate(self.layers):
             cls_only = cls_only_last and li == last
-            check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln1_w.data_ptr(), l.ln1_b.data_ptr(),
-                                       self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
-            self._mark("layernorm")
-            check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
-                                  _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d, st), "hcir_gemm_f16(qkv)")
+            if fuse and have_stats:
+                check(L.hcir_gemm_f16_fused(tok.data_ptr(), d, l.qkv_wg.data_ptr(), d, l.qkv_c2.data_ptr(), None,
+                                            m, 3 * d, d, _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d,
+                                            stats.data_ptr(), l.qkv_c1.data_ptr(), None, st),
+                      "hcir_gemm_f16_fused(ln1+qkv)")
+            else:
+                check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln1_w.data_ptr(),
+                                           l.ln1_b.data_ptr(), self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
+                self._mark("layernorm")
+                check(L.hcir_gemm_f16(ln.data_ptr(), d, l.qkv_w.data_ptr(), d, _p(l.qkv_b), None, m, 3 * d, d,
+                                      _lib.EPI_BIAS_F16, qkv.data_ptr(), 3 * d, st), "hcir_gemm_f16(qkv)")
+            have_stats = False
             self._mark("gemm_qkv")
             if not cls_only:
                 check(L.hcir_attn_fwd(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale, t,
                                       att.data_ptr(), st), "hcir_attn_fwd")
                 self._mark("attn")
-                check(L.hcir_gemm_f16(att.data_ptr(), d, l.proj_w.data_ptr(), d, l.proj_b.data_ptr(), _p(l.ls1),
-                                      m, d, d, self._resid_epi, tok.data_ptr(), d, st), "hcir_gemm_f16(proj)")
+                resid_gemm(att, d, l.proj_w, l.proj_b, l.ls1, fuse, "hcir_gemm_f16(proj)")
                 self._mark("gemm_proj")
-                check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln2_w.data_ptr(),
-                                           l.ln2_b.data_ptr(), self.eps, ln.data_ptr(), d, st), "hcir_layernorm_f16")
-                self._mark("layernorm")
-                check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
-                                      self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
-                      "hcir_gemm_f16(fc1)")
+                if fuse:
+                    check(L.hcir_gemm_f16_fused(tok.data_ptr(), d, l.fc1_wg.data_ptr(), d, l.fc1_c2.data_ptr(), None,
+                                                m, self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp,
+                                                stats.data_ptr(), l.fc1_c1.data_ptr(), None, st),
+                          "hcir_gemm_f16_fused(ln2+fc1)")
+                else:
+                    check(L.hcir_layernorm_f16(tok.data_ptr(), self._rt, m, d, d, l.ln2_w.data_ptr(),
+                                               l.ln2_b.data_ptr(), self.eps, ln.data_ptr(), d, st),
+                          "hcir_layernorm_f16")
+                    self._mark("layernorm")
+                    check(L.hcir_gemm_f16(ln.data_ptr(), d, l.fc1_w.data_ptr(), d, l.fc1_b.data_ptr(), None, m,
+                                          self.mlp, d, _lib.EPI_BIAS_GELU_F16, hid.data_ptr(), self.mlp, st),
+                          "hcir_gemm_f16(fc1)")
                 self._mark("gemm_fc1")
-                check(L.hcir_gemm_f16(hid.data_ptr(), self.mlp, l.fc2_w.data_ptr(), self.mlp, l.fc2_b.data_ptr(),
-                                      _p(l.ls2), m, d, self.mlp, self._resid_epi, tok.data_ptr(), d, st),
-                      "hcir_gemm_f16(fc2)")
+                # the row statistics after fc2 feed the NEXT block's ln_1 (none after the last block)
+                have_stats = fuse and li < last
+                resid_gemm(hid, self.mlp, l.fc2_w, l.fc2_b, l.ls2, have_stats, "hcir_gemm_f16(fc2)")
                 self._mark("gemm_fc2")
             else:
                 # class-token rows only: row b of the compact buffers <-> tok[b][0] (row stride t*d)

@@ -172,6 +172,31 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
                   const float* bias, const float* scale, int64_t m, int32_t n,
                   int32_t k, int epilogue, void* out, int64_t ldo, void* stream);
 
+/* LayerNorm fused into the GEMMs on either side of it (persistent 256 x 256 kernel only:
+ * hcir_gemm_fused_supported(m, n, k) != 0, i.e. M >= 1024, N % 256 == 0, K % 64 == 0).
+ * Replaces the  x -> norm1/ln_1 -> qkv   and   x -> norm2/ln_2 -> fc1   pairs of a Block
+ * (HP/src/models_vit.py:147-149; torchvision EncoderBlock via HP/src/main_backbone.py:554)
+ * without ever writing the normalised tokens:
+ *  (1) producer: epilogue HCIR_EPI_BIAS_RESID_F16 with stats_part != NULL also writes, per
+ *      stored fp16 row, partial (sum, sum of squares) slices
+ *          stats_part[slice][row][2],  slice < hcir_gemm_stats_slices(n) = n / 64;
+ *  (2) hcir_ln_stats_finalize adds the slices in index order (deterministic) and writes
+ *          ln_stats[row] = (mean, 1 / sqrt(var + eps)),  var = E[x^2] - mean^2 (biased);
+ *  (3) consumer: epilogue HCIR_EPI_BIAS_F16 / HCIR_EPI_BIAS_GELU_F16 with ln_stats, ln_c1:
+ *      A = the RAW residual rows x (fp16), W' = fp16(gamma o W),
+ *          out = act( rstd[m] * (A . W'^T - mean[m] * ln_c1[n]) + bias[n] )
+ *      where the caller prepares  ln_c1[n] = sum_k W'[n][k]  (of the ROUNDED fp16 values) and
+ *      bias[n] = sum_k beta[k] * W[n][k] + b[n]:  algebraically LayerNorm(x) . W^T + b.
+ * Exactly one of {ln_stats + ln_c1, stats_part} must be given.  scale as in hcir_gemm_f16. */
+int hcir_gemm_fused_supported(int64_t m, int32_t n, int32_t k);
+int32_t hcir_gemm_stats_slices(int32_t n);
+int hcir_gemm_f16_fused(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                        const float* scale, int64_t m, int32_t n, int32_t k, int epilogue,
+                        void* out, int64_t ldo, const float* ln_stats, const float* ln_c1,
+                        float* stats_part, void* stream);
+int hcir_ln_stats_finalize(const float* stats_part, int32_t slices, int64_t m, int32_t n_features,
+                           float eps, float* ln_stats, void* stream);
+
 /* Patch embedding = Conv2d(C, D, kernel=P, stride=P) as an im2col-free MFMA GEMM
  * over the fp32 NCHW image, fused with bias, class token and positional add:
  *   tok[b][0]     = cls + pos_mult * pos[0]

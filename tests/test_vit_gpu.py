@@ -96,6 +96,65 @@ def test_gemm_row_pitch(L, epi):
                            od.data_ptr(), ldo, _st()) == -1
 
 
+@pytest.mark.parametrize("m,d,mlp", [(1500, 256, 512), (197 * 6, 768, 3072)])
+def test_gemm_fused_layernorm(L, m, d, mlp):
+    """hcir_gemm_f16_fused: (1) the fp16-residual epilogue also emits per-row (sum, sumsq) slices ->
+    hcir_ln_stats_finalize -> (mean, rstd) of the STORED rows; (2) the consumer GEMM reads the raw rows and
+    applies LayerNorm algebraically.  Checked against torch LayerNorm + Linear (+ GELU) in fp32."""
+    g = torch.Generator().manual_seed(m + d)
+    eps = 1e-6
+    a = (torch.randn(m, mlp, generator=g) * 0.5).half()
+    w2 = (torch.randn(d, mlp, generator=g) * mlp ** -0.5).half()
+    b2 = torch.randn(d, generator=g)
+    # residual rows with a per-row offset (mean != 0) and a few large channels
+    resid = torch.randn(m, d, generator=g) + torch.randn(m, 1, generator=g) * 2.0
+    resid[:, 5] *= 20.0
+    resid = resid.half()
+    new_rows = (resid.float() + a.float() @ w2.float().t() + b2).half()          # what the epilogue stores
+    ad, wd, bd, od = a.cuda(), w2.cuda(), b2.cuda(), resid.cuda()
+    nsl = L.hcir_gemm_stats_slices(d)
+    assert nsl == d // 64 and L.hcir_gemm_fused_supported(m, d, mlp) == 1
+    part = torch.full((nsl, m, 2), float("nan"), device="cuda")
+    stats = torch.empty((m, 2), device="cuda")
+    assert L.hcir_gemm_f16_fused(ad.data_ptr(), mlp, wd.data_ptr(), mlp, bd.data_ptr(), None, m, d, mlp, 6,
+                                 od.data_ptr(), d, None, None, part.data_ptr(), _st()) == 0
+    assert L.hcir_ln_stats_finalize(part.data_ptr(), nsl, m, d, eps, stats.data_ptr(), _st()) == 0
+    got_rows = od.cpu()
+    np.testing.assert_allclose(got_rows.float().numpy(), new_rows.float().numpy(),
+                               atol=2e-3 * new_rows.float().abs().max().item(), rtol=0)
+    x = got_rows.double()                                   # statistics are those of the rows AS STORED
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    st_cpu = stats.cpu().double()
+    np.testing.assert_allclose(st_cpu[:, 0].numpy(), mean.numpy(), atol=1e-5 * x.abs().max().item(), rtol=0)
+    np.testing.assert_allclose(st_cpu[:, 1].numpy(), (var + eps).rsqrt().numpy(), rtol=2e-5)
+
+    # consumer: LayerNorm(x) @ W1^T + b1 (+ GELU) from the raw rows
+    gamma = 1.0 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.2 * torch.randn(d, generator=g)
+    w1 = torch.randn(mlp, d, generator=g) * d ** -0.5
+    b1 = torch.randn(mlp, generator=g)
+    wg = (w1.double() * gamma.double()[None, :]).half()
+    c1 = wg.double().sum(1).float()
+    c2 = (w1.double() @ beta.double() + b1.double()).float()
+    ref = F.layer_norm(got_rows.float(), (d,), gamma, beta, eps) @ w1.t() + b1
+    for epi, fn in ((0, lambda z: z), (1, F.gelu)):
+        out = torch.empty((m, mlp), dtype=torch.float16, device="cuda")
+        assert L.hcir_gemm_f16_fused(od.data_ptr(), d, wg.cuda().data_ptr(), d, c2.cuda().data_ptr(), None, m, mlp,
+                                     d, epi, out.data_ptr(), mlp, stats.data_ptr(), c1.cuda().data_ptr(), None,
+                                     _st()) == 0
+        torch.cuda.synchronize()
+        want = fn(ref)
+        np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(),
+                                   atol=3e-3 * max(1.0, want.abs().max().item()), rtol=0)
+    # argument checks: nothing fused / both / unsupported shapes and epilogues
+    assert L.hcir_gemm_f16_fused(od.data_ptr(), d, wd.data_ptr(), d, bd.data_ptr(), None, m, d, d, 0,
+                                 od.data_ptr(), d, None, None, None, _st()) == -1
+    assert L.hcir_gemm_f16_fused(ad.data_ptr(), mlp, wd.data_ptr(), mlp, bd.data_ptr(), None, 512, d, mlp, 6,
+                                 od.data_ptr(), d, None, None, part.data_ptr(), _st()) == -2
+    assert L.hcir_gemm_f16_fused(ad.data_ptr(), mlp, wd.data_ptr(), mlp, bd.data_ptr(), None, m, d, mlp, 0,
+                                 od.data_ptr(), d, None, None, part.data_ptr(), _st()) == -2
+
+
 def test_gemm_affine_epilogues(L):
     g = torch.Generator().manual_seed(5)
     m, n, k = 70, 512, 768
@@ -289,6 +348,31 @@ def test_vit_b16_batch_on_persistent_gemm(L):
     print(f"batch 8: embedding 1-cos = {_cos_err(got, ref):.2e}")
     assert _cos_err(got, ref) <= 1e-4
     assert _cos_err(got[:3], small) <= 1e-6
+
+
+def test_vit_b16_layernorm_fold_vs_separate(L, monkeypatch):
+    """fp16 residual stream, batch 8: LayerNorm folded into the GEMMs (default) and the separate
+    hcir_layernorm_f16 launches give the same embedding within fp16 noise, both within the oracle bar."""
+    from hcir import vit_engine
+    from hcir.main_backbone import SHAM2
+    monkeypatch.setattr(vit_engine, "DEFAULT_RESID_DTYPE", torch.float16)
+    torch.manual_seed(44)
+    model = SHAM2("vit_b_16").eval()
+    _randomize(model, 3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(12))
+    ref = ovit.sham2_extract_features(sd, x, "vit_b_16")
+    model = model.cuda()
+    outs = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(vit_engine, "LN_FUSE", fuse)
+        with torch.no_grad():
+            outs[fuse] = model.extract_features(x.cuda()).cpu()
+            full = model.backbone(x.cuda())[0].cpu()          # full last block (no CLS-only shortcut)
+        assert _cos_err(outs[fuse], full) <= 1e-6
+        print(f"LN fold {fuse}: embedding 1-cos vs oracle = {_cos_err(outs[fuse], ref):.2e}")
+        assert _cos_err(outs[fuse], ref) <= 1e-4
+    assert _cos_err(outs[True], outs[False]) <= 1e-5
 
 
 def test_vit_requires_no_grad_and_device(L):

@@ -148,6 +148,31 @@ def test_vit_large_patch14_config_c5_model():
     assert _cos_err(out[:, 0], ref[:, 0]) <= 1e-3
 
 
+def test_vit_large_patch14_fused_path(monkeypatch):
+    """ViT-L/14 at batch 4 (M = 1028 token rows): the persistent GEMM kernel with the fp16 residual stream and
+    LayerNorm folded into the GEMMs (slices of 1024 / 64 = 16), LayerScale gamma on the residual epilogues."""
+    from hcir import vit_engine
+    from hcir.models_vit import vit_large_patch14
+    monkeypatch.setattr(vit_engine, "DEFAULT_RESID_DTYPE", torch.float16)
+    torch.manual_seed(23)
+    m = vit_large_patch14(drop_path_rate=0.0, global_pool=True, init_values=0.1).eval()
+    _randomize(m, 24)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(25))
+    ref = ovit.models_vit_forward_features(sd, x, num_heads=16)
+    m = m.cuda()
+    outs = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(vit_engine, "LN_FUSE", fuse)
+        with torch.no_grad():
+            outs[fuse] = m.forward_features(x.cuda()).cpu()
+        print(f"ViT-L/14 LN fold {fuse}: CLS 1-cos = {_cos_err(outs[fuse][:, 0], ref[:, 0]):.2e}")
+        assert _cos_err(outs[fuse][:, 0], ref[:, 0]) <= 1e-3
+        # every token row, not only the class token
+        assert _cos_err(outs[fuse].reshape(-1, 1024), ref.reshape(-1, 1024)) <= 1e-3
+    assert _cos_err(outs[True].reshape(-1, 1024), outs[False].reshape(-1, 1024)) <= 1e-4
+
+
 def test_mae_extract_features():
     from hcir.backbone import MAE, vit_base_patch16_224
     torch.manual_seed(9)

@@ -68,6 +68,7 @@ struct ScanArgs {
   int* part_idx;
   int64_t nq, row_begin, row_end;  // gallery rows [row_begin, row_end)
   int d, k;
+  int shared_stream;  // > 1 query block reads every gallery tile: keep the stream in L2 (no `nt`)
 };
 
 template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS>
@@ -136,7 +137,10 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * Cfg::GM; };
   if (nsteps > 0) {
     if constexpr (GLDS) {
-      sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+      if (a.shared_stream)
+        sim_stage_glds<T, Cfg, 0>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+      else
+        sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
     } else {
       sim_stage_load<T, Cfg>(regs, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
       sim_stage_store<Cfg>(regs, lds, tid);
@@ -158,9 +162,14 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     const bool has_next = step + 1 < nsteps;
     if constexpr (GLDS) {
       sim_glds_retire_and_sync();  // DMA of stage `step` landed for every wave; slot cur^1 is free
-      if (has_next)
-        sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q,
-                               q_row0, q_last, a.d, nkc_next, tid);
+      if (has_next) {
+        if (a.shared_stream)
+          sim_stage_glds<T, Cfg, 0>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q, q_row0,
+                                    q_last, a.d, nkc_next, tid);
+        else
+          sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last,
+                                                q, q_row0, q_last, a.d, nkc_next, tid);
+      }
       sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
     } else {
       if (has_next)
@@ -465,6 +474,17 @@ struct Plan {
 
 constexpr int kMaxGridX = 512;  // 2 workgroups per CU; also <= 576 lists per merge pass
 
+// Workgroups along the gallery for `qblocks` query blocks.  Every query block scans every gallery tile; the
+// grid is sized so that ALL (tile run, query block) workgroups are resident at once (512 slots) and the blocks
+// of one tile run sit on the same XCD (linear id = x + grid_x * y, grid_x a multiple of 8): they stream the
+// same tiles in step and all but the first read them from that XCD's L2.  (With 512 workgroups per query
+// block the blocks ran one after the other and the gallery came from HBM once per block.)
+inline int scan_grid_x(int64_t tiles, int64_t qblocks) {
+  int64_t cap = kMaxGridX / (qblocks < 1 ? 1 : qblocks);
+  cap = cap < 8 ? 8 : (cap & ~int64_t(7));
+  return (int)(tiles < cap ? tiles : cap);
+}
+
 Plan make_plan(int64_t nq, int64_t ng, int k) {
   Plan p;
   p.kp = k <= 16 ? 16 : (k <= 32 ? 32 : 64);
@@ -587,6 +607,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int merge_grid = (int)hcir_cdiv(nq, 4);
 
+  const int64_t qblocks = hcir_cdiv(nq, p.qb);
   ScanArgs a{};
   a.q = q;
   a.g = g;
@@ -596,6 +617,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   a.part_idx = w.part_idx;
   a.nq = nq;
   a.d = d;
+  a.shared_stream = qblocks > 1 ? 1 : 0;
 
   if (p.npass == 1) {
     a.k = k;
@@ -604,7 +626,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     a.row_begin = 0;
     a.row_end = p.prefix;
     const int64_t tiles_a = hcir_cdiv(p.prefix, p.gm);
-    const int grid_a = (int)(tiles_a < kMaxGridX ? tiles_a : kMaxGridX);
+    const int grid_a = scan_grid_x(tiles_a, qblocks);
     launch_scan_dtype(dtype, p, a, grid_a, st);
     HCIR_LAUNCH_CHECK();
     MergeArgs<int> m{};
@@ -632,7 +654,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     a.row_end = ng;
     a.floor_val = w.floor_val;
     const int64_t tiles_b = hcir_cdiv(ng - p.prefix, p.gm);
-    const int grid_b = (int)(tiles_b < kMaxGridX ? tiles_b : kMaxGridX);
+    const int grid_b = scan_grid_x(tiles_b, qblocks);
     launch_scan_dtype(dtype, p, a, grid_b, st);
     HCIR_LAUNCH_CHECK();
     MergeArgs<int> m2{};
@@ -656,7 +678,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   // k > 64: successive passes of <= 64 ranks below a moving ceiling.
   a.row_begin = 0;
   a.row_end = ng;
-  const int grid_x = p.grid_main;
+  const int grid_x = scan_grid_x(hcir_cdiv(ng, p.gm), qblocks);
   int done = 0;
   for (int pass = 0; pass < p.npass; ++pass) {
     const int kk = (k - done) < 64 ? (k - done) : 64;

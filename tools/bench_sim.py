@@ -28,7 +28,7 @@ def run(nq, ng, d, k, dtype, iters=10):
 if __name__ == "__main__":
     ng = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     for dtype in (torch.float32, torch.float16):
-        for nq in (1, 32, 64, 128, 256):
-            run(nq, ng, 768, 10, dtype)
+        for nq in (1, 32, 64, 128, 220, 256, 512, 1760):
+            run(nq, ng, 768, 10 if nq != 220 else 16, dtype)
     run(64, 10_000, 768, 10, torch.float32)
     run(64, 10_000, 768, 10, torch.float16)

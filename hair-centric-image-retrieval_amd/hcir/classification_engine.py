@@ -63,7 +63,11 @@ class Classifier:
     def _embed(self, loader, feats, labels):
         for batch in loader:
             images, lab = batch[0], batch[1]
-            f = self.model.extract_features(images.to(self.device))
+            images = images.to(self.device)
+            if images.dtype == torch.uint8:  # raw RGB8 windows [B,H,W,3]: ToTensor + Normalize on the device
+                from .transform import knn_transform_u8
+                images = knn_transform_u8(images)
+            f = self.model.extract_features(images)
             feats.append(ops.l2_normalize(f.float().contiguous()))  # F.normalize(dim=1), stays in HBM
             labels.append(torch.as_tensor(lab))
 

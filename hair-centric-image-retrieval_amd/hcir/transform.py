@@ -1,6 +1,11 @@
 """hcir.transform — knn_transform (HP/utils/transform.py:10-14) without torchvision:
 CenterCrop(224) -> ToTensor -> Normalize(ImageNet mean/std).  No resize (the resize variant is
-commented out in the reference, :15-19).  Host-side input contract of the embed path."""
+commented out in the reference, :15-19).
+
+`knn_transform(pil)` is the host form (PIL + numpy) with the reference's signature;
+`knn_transform_u8(batch)` runs the same arithmetic on the HIP device over decoded RGB8 images
+(hcir_knn_transform_u8): the loader ships bytes (4x less H2D traffic than fp32) and the float work
+leaves the DataLoader workers."""
 from __future__ import annotations
 
 import numpy as np
@@ -22,3 +27,41 @@ def knn_transform(image, size: int = 224) -> torch.Tensor:
     win = arr[top:top + size, left:left + size].astype(np.float32) / np.float32(255.0)
     win = (win - _MEAN) / _STD
     return torch.from_numpy(np.ascontiguousarray(win.transpose(2, 0, 1)))
+
+
+def knn_transform_u8(images: torch.Tensor, size: int = 224) -> torch.Tensor:
+    """uint8 [B, H, W, 3] (or [H, W, 3]) on the HIP device -> float32 [B, 3, size, size]; bit-identical to
+    knn_transform applied image by image.  No CPU path."""
+    from . import _lib
+    from ._lib import HcirError, check
+    import ctypes
+    if images.dtype != torch.uint8:
+        raise HcirError(f"knn_transform_u8 takes uint8 RGB images, got {images.dtype}")
+    if not images.is_cuda:
+        raise HcirError(f"images are on {images.device}; knn_transform_u8 runs on a HIP device only")
+    if images.dim() == 3:
+        images = images[None]
+    if images.dim() != 4 or images.shape[-1] != 3:
+        raise HcirError(f"expected [B, H, W, 3], got {tuple(images.shape)}")
+    images = images.contiguous()
+    b, h, w, _ = images.shape
+    out = torch.empty((b, 3, size, size), dtype=torch.float32, device=images.device)
+    mean = (ctypes.c_float * 3)(*_MEAN.tolist())
+    std = (ctypes.c_float * 3)(*_STD.tolist())
+    check(_lib.lib().hcir_knn_transform_u8(images.data_ptr(), b, h, w, size, mean, std, out.data_ptr(),
+                                           torch.cuda.current_stream(images.device).cuda_stream),
+          "hcir_knn_transform_u8")
+    return out
+
+
+def center_window_u8(image, size: int = 224) -> torch.Tensor:
+    """PIL image -> uint8 [size, size, 3]: the CenterCrop window only (zero-padded when the image is
+    smaller), for loaders that leave ToTensor + Normalize to knn_transform_u8 on the device."""
+    arr = np.asarray(image.convert("RGB"))
+    h, w = arr.shape[:2]
+    if h < size or w < size:
+        ph, pw = max(size - h, 0), max(size - w, 0)
+        arr = np.pad(arr, ((ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2), (0, 0)))
+        h, w = arr.shape[:2]
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return torch.from_numpy(np.ascontiguousarray(arr[top:top + size, left:left + size]))

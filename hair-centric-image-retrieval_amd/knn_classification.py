@@ -96,7 +96,13 @@ def build_model(args):
 def main(args):
     from hcir.classification_engine import Classifier
     from hcir.dataloader import CustomDataset
-    from hcir.transform import knn_transform
+    # HCIR_HOST_TRANSFORM=1: the reference's host-side knn_transform (fp32 tensors from the workers).
+    # Default: the workers ship the RGB8 centre window and ToTensor + Normalize run on the device
+    # (hcir_knn_transform_u8, bit-identical arithmetic, 4x less H2D traffic)
+    if os.environ.get("HCIR_HOST_TRANSFORM", "0") == "1":
+        from hcir.transform import knn_transform
+    else:
+        from hcir.transform import center_window_u8 as knn_transform
 
     train_dataset = CustomDataset(args.train_annotation, args.img_dir, knn_transform)
     test_dataset = CustomDataset(args.test_annotation, args.img_dir, knn_transform)

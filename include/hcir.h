@@ -239,6 +239,14 @@ int hcir_patch_mean(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_
                     const float* gamma, const float* beta, float eps, float* out_f32,
                     void* stream);
 
+/* knn_transform on the device (HP/utils/transform.py:10-14): CenterCrop(size) -> ToTensor ->
+ * Normalize(mean, std) of a batch of decoded RGB8 images of one size, img [B][H][W][3] uint8 (device)
+ * -> out [B][3][size][size] fp32.  Bit-exact with torchvision's arithmetic (u8 / 255, (x - mean) / std,
+ * IEEE fp32); images smaller than the window are zero-padded as CenterCrop does.  mean3 / std3 are
+ * HOST pointers to 3 floats. */
+int hcir_knn_transform_u8(const uint8_t* img, int64_t b, int32_t h, int32_t w, int32_t size,
+                          const float* mean3, const float* std3, float* out, void* stream);
+
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 

@@ -384,3 +384,40 @@ def test_index_flat_l2(tmp_path):
     assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
     hidx.save_paths(["a.png", "b.png"], str(tmp_path / "paths.pkl"))
     assert hidx.load_paths(str(tmp_path / "paths.pkl")) == ["a.png", "b.png"]
+
+
+# ------------------------------------------------------------------ knn_transform on the device (a1)
+@pytest.mark.parametrize("h,w", [(224, 224), (1024, 1024), (301, 257), (225, 640), (100, 300), (223, 222)])
+def test_knn_transform_u8_bit_exact(h, w):
+    """hcir_knn_transform_u8 == CenterCrop(224) -> ToTensor -> Normalize element for element (IEEE fp32),
+    including odd differences (Python round half to even) and images smaller than the window (zero pad)."""
+    from PIL import Image
+    from hcir.transform import center_window_u8, knn_transform, knn_transform_u8
+    rng = np.random.default_rng(h * 1000 + w)
+    imgs = rng.integers(0, 256, size=(3, h, w, 3), dtype=np.uint8)
+    got = knn_transform_u8(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    for i in range(3):
+        pil = Image.fromarray(imgs[i])
+        ref = knn_transform(pil).numpy()                      # host form, same contract as the reference's
+        np.testing.assert_array_equal(got[i], ref)
+        if h >= 224 and w >= 224:
+            np.testing.assert_array_equal(ref, otf.knn_transform(pil))      # oracle restatement
+        # loaders may ship the window only: same result
+        win = center_window_u8(pil)
+        assert win.dtype == torch.uint8 and tuple(win.shape) == (224, 224, 3)
+        np.testing.assert_array_equal(knn_transform_u8(win.cuda())[0].cpu().numpy(), ref)
+
+
+def test_knn_transform_u8_goldens_and_errors(golden_dir):
+    from hcir import HcirError
+    from hcir.transform import knn_transform_u8
+    z = np.load(os.path.join(golden_dir, "asset_windows.npz"))
+    wins = z["windows"] if "windows" in z else z[z.files[0]]
+    assert wins.dtype == np.uint8 and wins.shape[1:] == (224, 224, 3)
+    got = knn_transform_u8(torch.from_numpy(wins).cuda()).cpu().numpy()
+    for i in range(wins.shape[0]):
+        np.testing.assert_array_equal(got[i], otf.window_to_tensor(wins[i]))
+    with pytest.raises(HcirError):
+        knn_transform_u8(torch.zeros(1, 224, 224, 3, dtype=torch.uint8))          # CPU tensor: no fallback
+    with pytest.raises(HcirError):
+        knn_transform_u8(torch.zeros(1, 224, 224, 3, device="cuda"))               # not uint8

@@ -223,23 +223,19 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
         scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
     }
   }
-  // LayerNorm fold, out = rstd[m] acc + (-rstd[m] mean[m]) c1[n] + bias[n]:
-  //   accumulator side: acc * rstd of the 4 (2) rows this lane owns there, before the fp16 image;
-  //   row side: the rank-1 term u[row] * c1[n] with u = -rstd * mean of the 8 rows this lane stores.
-  float ln_rstd[4], ln_u[8];
+  // LayerNorm fold, out = rstd[m] acc + (-rstd[m] mean[m]) c1[n] + bias[n], all on the row side: the fp16
+  // image holds the raw accumulators (same relative rounding as a pre-scaled image; |acc| stays far below
+  // the fp16 range: it is a 768..4096-term dot product of fp16 residual values with LayerNorm-scaled weights),
+  // then x = rstd[row] * v + (u[row] * c1[n] + bias[n]) with u = -rstd * mean for the 8 rows this lane stores.
+  float ln_rs[8], ln_u[8];
   f32x4 c1r[NPASS][NB];
   if constexpr (kLn) {
-#pragma unroll
-    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) {
-      int64_t mm = m0w + (MF16 ? 16 * mt + (lane & 15) : 32 * mt + r);
-      mm = mm < g.m ? mm : g.m - 1;
-      ln_rstd[mt] = g.ln_stats[2 * mm + 1];
-    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int64_t mm = m0w + it * 8 + rrow;
       mm = mm < g.m ? mm : g.m - 1;
       const f32x2 ms = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * mm);
+      ln_rs[it] = ms[1];
       ln_u[it] = -ms[0] * ms[1];
     }
 #pragma unroll
@@ -251,9 +247,10 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (kLn) {
 #pragma unroll
-    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) asm volatile("" : "+v"(ln_rstd[mt]));
-#pragma unroll
-    for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(ln_u[it]));
+    for (int it = 0; it < 8; ++it) {
+      asm volatile("" : "+v"(ln_rs[it]));
+      asm volatile("" : "+v"(ln_u[it]));
+    }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
@@ -281,13 +278,8 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
               f16x4 o;
-              if constexpr (kLn) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)(ln_rstd[mt] * acc.a[nt][mt][4 * grp + e]);
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
-              }
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
               const int chunk = q * 4 + grp;
               *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
             }
@@ -313,13 +305,8 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           for (int q = 0; q < 4; ++q) {   // 64 features per pass = 4 n-tiles of 16
             const int nt = 4 * pass + q;
             f16x4 o;
-            if constexpr (kLn) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)(ln_rstd[mt] * acc.a[nt][mt][e]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
-            }
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
             const int chunk = 2 * q + (q16 >> 1);
             *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
           }
@@ -363,9 +350,11 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
               x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
             } else if constexpr (kResidH) {
               x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
+            } else if constexpr (kLn) {
+              x = __builtin_fmaf(ln_rs[it0 + u], x, __builtin_fmaf(ln_u[it0 + u], c1r[pass][e >> 2][e & 3], bb));
+              if constexpr (kGelu) x = gelu_erf(x);
             } else {
               x += bb;
-              if constexpr (kLn) x = __builtin_fmaf(ln_u[it0 + u], c1r[pass][e >> 2][e & 3], x);
               if constexpr (kGelu) x = gelu_erf(x);
             }
             o[e] = (_Float16)x;

@@ -18,25 +18,30 @@ namespace {
 
 using GemmCfg = SimCfg<_Float16, 2, 2, 2>;  // GM = 128 W rows, QB = 128 A rows
 
-// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
-// far below the fp16 rounding of the output): 1 rcp + 1 exp2 + 7 fma instead of erff's ~40
-// instructions — the fc1 epilogue evaluates it 16K times per wave tile.
-__device__ __forceinline__ float gelu_erf(float x) {
-  // erfc(z) ~ P(t) t exp(-z^2), t = 1/(1 + p z), z = |x|/sqrt2 (A&S 7.1.26);
-  // gelu(x) = x * 0.5 * erfc(-x/sqrt2) = max(x, 0) - |x| * q,  q = 0.5 * erfc(z)  (both signs of x).
-  // Constants folded: w = z * sqrt(log2 e) so that exp(-z^2) = exp2(-w^2); 0.5 folded into P.
-  constexpr float kW = 0.70710678118654752440f * 1.20112240878645f;   // 1/sqrt2 * sqrt(log2 e)
-  constexpr float kP = 0.3275911f / 1.20112240878645f;                // p / sqrt(log2 e)
-  const float w = fabsf(x) * kW;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(kP, w, 1.0f));
-  float p = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
-  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-(w * w));
-  const float q = p * t * e;
-  return __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// fp16 rounding of the output) instead of erff's ~40 instructions: the fc1 epilogue evaluates it 64K times per
+// tile and is VALU-bound there.  With q = (1/2) erfc(|x|/sqrt2) = P(t) t exp(-x^2/2), t = 1/(1 + p|x|/sqrt2):
+//   gelu(x) = max(x,0) - |x| q = |x| (1/2 - q) + x/2
+// (no max, no sign select; exact 0 / x in the tails), arranged so that hipcc emits packed fp32 ops on pairs:
+// 8.5 VALU instructions per element (3.5 v_pk_fma + 2 v_pk_mul + v_and + v_rcp + v_exp), 11.5 before.
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
+  constexpr float kPW = 0.3275911f * 0.70710678118654752440f;      // p / sqrt2
+  constexpr float kNW2 = -0.5f * 1.44269504088896340736f;          // exp(-x^2/2) = exp2(kNW2 x^2)
+  const gelu_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const gelu_f32x2 den = ax * kPW + 1.0f;
+  const gelu_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  gelu_f32x2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+  p = p * t + (0.5f * 1.421413741f);
+  p = p * t + (0.5f * -0.284496736f);
+  p = p * t + (0.5f * 0.254829592f);
+  const gelu_f32x2 s = (x * x) * kNW2;
+  const gelu_f32x2 e = {__builtin_amdgcn_exp2f(s[0]), __builtin_amdgcn_exp2f(s[1])};
+  const gelu_f32x2 pt = p * t;
+  const gelu_f32x2 qn = 0.5f - pt * e;
+  return ax * qn + 0.5f * x;
 }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((gelu_f32x2){x, x})[0]; }
 
 // Internal epilogue codes of hcir_gemm_f16_fused (persistent kernel only), beyond hcir_epilogue:
 //   EPI_RESID_F16_STATS: BIAS_RESID_F16 that also writes per-row partial (sum, sum of squares) of the stored
@@ -342,6 +347,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           const int row = (it0 + u) * 8 + rrow;
           const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
           f16x8 o;
+          float xs[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = (float)v[e];
@@ -352,13 +358,21 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
               x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
             } else if constexpr (kLn) {
               x = __builtin_fmaf(ln_rs[it0 + u], x, __builtin_fmaf(ln_u[it0 + u], c1r[pass][e >> 2][e & 3], bb));
-              if constexpr (kGelu) x = gelu_erf(x);
             } else {
               x += bb;
-              if constexpr (kGelu) x = gelu_erf(x);
             }
-            o[e] = (_Float16)x;
+            xs[e] = x;
           }
+          if constexpr (kGelu) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
+              xs[e] = y[0];
+              xs[e + 1] = y[1];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)xs[e];
           const int64_t m = m0w + row;
           if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
           if constexpr (EPI == EPI_RESID_F16_STATS) {

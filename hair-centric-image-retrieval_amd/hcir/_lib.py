@@ -17,7 +17,8 @@ import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
-LIB_PATH = os.path.join(CSRC_DIR, "libhcir.so")
+# HCIR_LIB_PATH: load another build of the same sources (A/B and ablation builds under tools/); default in-tree
+LIB_PATH = os.environ.get("HCIR_LIB_PATH") or os.path.join(CSRC_DIR, "libhcir.so")
 
 F32, F16, BF16 = 0, 1, 2
 EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_AFFINE_RELU_F16, EPI_AFFINE_F32, \

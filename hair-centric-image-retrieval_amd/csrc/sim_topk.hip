@@ -20,6 +20,7 @@
 //   k > 64 : repeated passes, each taking the next <=64 ranks below a per-query
 //            ceiling (val, idx) left by the previous pass.
 #include "sim_core.h"
+#include <stdlib.h>
 
 #ifndef HCIR_SCAN_AUX
 #define HCIR_SCAN_AUX 2  // cache policy of the once-read gallery stream: 2 = nt (non-temporal), +5 % GB/s
@@ -69,6 +70,7 @@ struct ScanArgs {
   int64_t nq, row_begin, row_end;  // gallery rows [row_begin, row_end)
   int d, k;
   int shared_stream;  // > 1 query block reads every gallery tile: keep the stream in L2 (no `nt`)
+  const int* gate;    // optional device flag: the launch does nothing unless *gate != 0 (fallback of the big scan)
 };
 
 template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS>
@@ -80,8 +82,12 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   constexpr int QR_FIT = Cfg::LDS_BYTES / (NSRC * KP * 8);
   constexpr int QR = QR_FIT >= Cfg::QB ? Cfg::QB : (QR_FIT >= 64 ? 64 : (QR_FIT >= 32 ? 32 : 16));
   static_assert(QR * NSRC * KP * 8 <= Cfg::LDS_BYTES, "merge round must fit LDS");
-  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  // LDS-DMA stage ring.  KP = 64 runs one workgroup per CU (128 list registers per lane): a 4-slot ring keeps
+  // three stages (108 KB) in flight per CU instead of one; the 2-workgroup configurations keep two slots each.
+  constexpr int NST = (GLDS && KP == 64) ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) char lds[NST * Cfg::STAGE_BYTES];
 
+  if (a.gate && *a.gate == 0) return;  // uniform: every wave of the grid reads the same flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_g = wave / WQ, wave_q = wave % WQ;
   const int r = lane & 31, h = lane >> 5;
@@ -135,12 +141,26 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   // staging one stage ahead with zero fill past d.
   u32x4 regs[GLDS ? 1 : Cfg::NLOAD];
   auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * Cfg::GM; };
+  // stage s of this workgroup = (tile s / nkc, chunk s % nkc); the issue cursor runs NST-1 stages ahead
+  int64_t issue_tile = 0;
+  int issue_kc = 0;
+  auto issue_stage = [&](int slot) {
+    if (a.shared_stream)
+      sim_stage_glds<T, Cfg, 0>(lds + slot * Cfg::STAGE_BYTES, g, tile_row0(issue_tile), g_last, q, q_row0, q_last,
+                                a.d, issue_kc, tid);
+    else
+      sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + slot * Cfg::STAGE_BYTES, g, tile_row0(issue_tile), g_last, q,
+                                            q_row0, q_last, a.d, issue_kc, tid);
+    if (++issue_kc == nkc) {
+      issue_kc = 0;
+      ++issue_tile;
+    }
+  };
   if (nsteps > 0) {
     if constexpr (GLDS) {
-      if (a.shared_stream)
-        sim_stage_glds<T, Cfg, 0>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
-      else
-        sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
+#pragma unroll
+      for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nsteps) issue_stage(s0);
     } else {
       sim_stage_load<T, Cfg>(regs, g, tile_row0(0), g_last, q, q_row0, q_last, a.d, 0, tid);
       sim_stage_store<Cfg>(regs, lds, tid);
@@ -150,8 +170,8 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
 
   int64_t tile_i = 0;  // index among my tiles
   int kc = 0;
+  int cur = 0;         // ring slot of stage `step`
   for (int64_t step = 0; step < nsteps; ++step) {
-    const int cur = (int)(step & 1);
     // next stage (possibly first chunk of my next tile)
     int nkc_next = kc + 1;
     int64_t ntile_i = tile_i;
@@ -161,15 +181,18 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     }
     const bool has_next = step + 1 < nsteps;
     if constexpr (GLDS) {
-      sim_glds_retire_and_sync();  // DMA of stage `step` landed for every wave; slot cur^1 is free
-      if (has_next) {
-        if (a.shared_stream)
-          sim_stage_glds<T, Cfg, 0>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last, q, q_row0,
-                                    q_last, a.d, nkc_next, tid);
-        else
-          sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + (cur ^ 1) * Cfg::STAGE_BYTES, g, tile_row0(ntile_i), g_last,
-                                                q, q_row0, q_last, a.d, nkc_next, tid);
+      // Stage `step` landed for every wave: the NST-2 younger stages may stay in flight (vmcnt retires in
+      // order; the only other vector-memory operations of the loop are the optional gallery-norm loads of the
+      // tile epilogue, whose consumers already waited for everything older).  Near the tail fewer stages
+      // are outstanding than the count allows: wait for all.
+      if (NST > 2 && !a.gn && step + NST - 1 <= nsteps) {
+        if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::NLOAD) : "memory");
+        __syncthreads();
+      } else {
+        sim_glds_retire_and_sync();
       }
+      // the slot read in step-1 is free after this barrier: issue stage step+NST-1 into it
+      if (step + NST - 1 < nsteps) issue_stage((cur + NST - 1) % NST);
       sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
     } else {
       if (has_next)
@@ -235,6 +258,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     if constexpr (!GLDS) __syncthreads();
     kc = nkc_next;
     tile_i = ntile_i;
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
   __syncthreads();  // every wave is done with the stage buffers before they are re-used below
 
@@ -288,6 +312,198 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
 }
 
 // --------------------------------------------------------------------------
+// Big-tile scan of the rows behind the prefix, for MANY queries (nq > 128, k <= 16, fp16 / bf16, d % 64 == 0).
+//
+// With >128 queries the scan is MFMA-bound and the 128 x 128 tile of sim_topk_scan (64 x 64 per wave) tops
+// out near 0.45-0.55 PFLOP/s; the 256 x 256 tile of the ViT GEMM (gemm.hip: 8 waves, 128 x 64 per wave, two
+// 64 KB LDS slots filled by LDS-DMA) runs the same product at about twice that.  Its 128 accumulators leave no
+// room for per-lane top-k lists, and it does not need them: behind the prefix floor a candidate is RARE
+// (a row enters only if it beats the k-th score of the first rows: ~15 k rows per query in a gallery in
+// random order), so the kernel keeps no lists at all - a lane that sees score > floor appends (score, row) to
+// the query's candidate buffer through an atomic counter.  The final merge takes the prefix list plus the
+// <= cap candidates as one-element lists.  If any query overflows its buffer (a gallery whose later rows
+// systematically beat its first ones) a device flag is raised and the list-keeping scan runs instead, gated
+// on that flag: exact either way, no host round trip.
+//
+// MFMA operands, k-order and accumulation are those of sim_topk_scan (32x32x16, gallery row on the MFMA row,
+// query on the column, chunks 2ks+h of a 64-wide stage): the scores are bit-identical to that kernel's.
+// --------------------------------------------------------------------------
+struct BigScanArgs {
+  const void* q;
+  const void* g;
+  const float* floor_val;  // [nq] k-th score of the prefix
+  float* cand_val;         // [cap][nq]
+  int* cand_idx;           // [cap][nq]
+  int* cand_cnt;           // [nq], zeroed by the caller
+  int* overflow;           // [1],  zeroed by the caller
+  int64_t nq, row_begin, row_end;
+  int d, cap;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void sim_scan_big_kernel(BigScanArgs a) {
+  constexpr int STAGE = 512 * 128;  // 256 gallery rows then 256 query rows, 128 B (64 elements) each
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_g = wave >> 2, wave_q = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t q_row0 = (int64_t)blockIdx.y * 256;
+  const int nkc = a.d / 64;
+  const int64_t nrows = a.row_end - a.row_begin;
+  const int64_t ntiles = (nrows + 255) / 256;
+  const int64_t my_tiles =
+      (int64_t)blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t nsteps = my_tiles * nkc;
+  auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * 256; };
+
+  float flo[2];
+  int64_t myq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    myq[qt] = q_row0 + wave_q * 64 + qt * 32 + r;
+    flo[qt] = myq[qt] < a.nq ? a.floor_val[myq[qt]] : __builtin_huge_valf();  // padding queries never match
+  }
+
+  // DMA sources: piece = tid + 512 i -> LDS row piece>>3, physical 16-B slot piece&7 holding logical chunk
+  // slot ^ ((row>>1)&7).  Pieces 0..3 are gallery rows (offsets from the tile's first row, clamped to the last
+  // gallery row), 4..7 query rows (the same for every tile, clamped to the last query).
+  const char* qbase = static_cast<const char*>(a.q) + q_row0 * a.d * (int64_t)sizeof(T);
+  const char* gbase = nullptr;
+  uint32_t goff[4], qoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = tid + 512 * (4 + i);
+    const int row = (piece >> 3) - 256, chunk = (piece & 7) ^ ((((piece >> 3)) >> 1) & 7);
+    int64_t qr = row;
+    qr = q_row0 + qr > a.nq - 1 ? a.nq - 1 - q_row0 : qr;
+    qoff[i] = (uint32_t)((qr * a.d + chunk * 8) * (int64_t)sizeof(T));
+  }
+  int64_t issue_tile = 0;
+  int issue_kc = 0;
+  auto set_gallery_sources = [&](int64_t ti) {
+    const int64_t r0 = tile_row0(ti);
+    gbase = static_cast<const char*>(a.g) + r0 * a.d * (int64_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = tid + 512 * i;
+      const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
+      int64_t gr = row;
+      gr = r0 + gr > a.row_end - 1 ? a.row_end - 1 - r0 : gr;
+      goff[i] = (uint32_t)((gr * a.d + chunk * 8) * (int64_t)sizeof(T));
+    }
+  };
+  auto issue_piece = [&](int slot, int i) {  // i is a constant after unrolling
+    const char* sp = (i < 4 ? gbase + goff[i & 3] : qbase + qoff[i & 3]) + issue_kc * 128;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                     (__attribute__((address_space(3))) void*)(lds + slot * STAGE +
+                                                                                ((tid & ~63) + 512 * i) * 16),
+                                     16, 0, 0);
+  };
+  auto issue_advance = [&]() {
+    if (++issue_kc == nkc) {
+      issue_kc = 0;
+      ++issue_tile;
+      if (issue_tile < my_tiles) set_gallery_sources(issue_tile);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[gt][qt][i] = 0.f;
+
+  if (nsteps > 0) {
+    set_gallery_sources(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_piece(0, i);
+    issue_advance();
+  }
+
+  int kc = 0;
+  int64_t ti = 0;
+  for (int64_t step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: see sim_glds_retire_and_sync()
+    __builtin_amdgcn_s_barrier();
+    const char* st = lds + (step & 1) * STAGE;
+    const bool do_issue = step + 1 < nsteps;
+    const int islot = (int)((step + 1) & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = 2 * ks + h;
+      u32x4 af[4], bf[2];
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt)
+        af[gt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_g * 128 + gt * 32 + r, chunk));
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+        bf[qt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_q * 64 + qt * 32 + r, chunk));
+      if (do_issue && ks < 2) {  // four of the eight DMA pieces of stage step+1 per early k-substep
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * ks + i);
+      }
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          if constexpr (__is_same(T, _Float16))
+            acc[gt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[gt]),
+                                                                 __builtin_bit_cast(f16x8, bf[qt]), acc[gt][qt], 0, 0, 0);
+          else
+            acc[gt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[gt]),
+                                                                  __builtin_bit_cast(bf16x8, bf[qt]), acc[gt][qt], 0, 0, 0);
+        }
+    }
+    if (do_issue) issue_advance();
+
+    if (++kc == nkc) {
+      // ---- tile epilogue: compare against the floor; candidates are rare -> one ballot per 32 x 32 tile
+      const int64_t row0 = tile_row0(ti) + wave_g * 128;
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) {
+        const int64_t rbase = row0 + gt * 32 + 4 * h;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          unsigned mask = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int64_t row = rbase + (i & 3) + 8 * (i >> 2);
+            const bool cand = (row < a.row_end) && (acc[gt][qt][i] > flo[qt]);
+            mask |= cand ? (1u << i) : 0u;
+          }
+          if (__ballot(mask != 0u) != 0ull) {
+            unsigned any = mask;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
+            any = __builtin_amdgcn_readfirstlane(any);
+            while (any != 0u) {  // wave-uniform slot loop: acc[..][i] with a scalar i stays in registers
+              const int i = __builtin_ctz(any);
+              any &= any - 1u;
+              const float sc = acc[gt][qt][i];
+              if ((mask >> i) & 1u) {
+                const int pos = atomicAdd(a.cand_cnt + myq[qt], 1);
+                if (pos < a.cap) {
+                  a.cand_val[(int64_t)pos * a.nq + myq[qt]] = sc;
+                  a.cand_idx[(int64_t)pos * a.nq + myq[qt]] = (int)(rbase + (i & 3) + 8 * (i >> 2));
+                } else {
+                  *a.overflow = 1;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[gt][qt][i] = 0.f;
+        }
+      }
+      kc = 0;
+      ++ti;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // merge: one wave per query; lists [nlists][nq][kin] sorted (desc, idx asc),
 // empty slots have idx < 0.  Lane l owns lists l, l+64, ... (<= LPL of them) and
 // caches each list's head; k_out rounds of wave arg-max.
@@ -309,6 +525,9 @@ struct MergeArgs {
   const float* extra_val;
   const int* extra_idx;
   int kin_extra;
+  const int* nlists_q;   // optional [nq]: lists of this query = min(nlists_q[q], nlists) (candidate buffers)
+  const int* gate;       // optional device flag: run only if (*gate != 0) == (gate_want != 0)
+  int gate_want;
 };
 
 template <typename IdxT>
@@ -316,7 +535,10 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
   const int lane = threadIdx.x & 63;
   const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= a.nq) return;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
   const bool has_extra = a.extra_val != nullptr;
+  int nl = a.nlists;
+  if (a.nlists_q) nl = a.nlists_q[qi] < nl ? a.nlists_q[qi] : nl;
   const int total = a.nlists + (has_extra ? 1 : 0);
 
   float cv[kMergeLPL];
@@ -326,7 +548,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
     v = kNegInf;
     id = -1;
     if (list < a.nlists) {
-      if (pos < a.kin) {
+      if (pos < a.kin && list < nl) {
         const int64_t o = ((int64_t)list * a.nq + qi) * a.kin + pos;
         v = a.vals[o];
         id = (int64_t)a.idx[o];
@@ -501,13 +723,20 @@ Plan make_plan(int64_t nq, int64_t ng, int k) {
   p.prefix = ng;
   if (p.npass == 1 && ng >= 32768) {
     int64_t s = ng / 16;
-    const int64_t lo = 8192, hi = 131072;
+    // 64-entry lists: a workgroup's fixed cost (filling the lists from its first tile, then the in-workgroup
+    // merge: ~85 us) dwarfs its streaming time, so the prefix is ONE round of at most 64 workgroups x 1 tile;
+    // 16 K rows still put the floor within ~k ln(N/16K) insertions per query of the final k-th score
+    const int64_t lo = 8192, hi = p.kp == 64 ? 16384 : 131072;
     s = s < lo ? lo : (s > hi ? hi : s);
     s = hcir_cdiv(s, p.gm) * p.gm;
     if (s < ng) p.prefix = s;
   }
   return p;
 }
+
+// candidates per query the big-tile scan can hold: one-element lists of the final merge, next to the prefix
+// list (kMergeLPL * 64 = 576 lists per pass)
+constexpr int kCandCap = 512;
 
 struct Workspace {
   float* part_val;
@@ -517,6 +746,9 @@ struct Workspace {
   float* floor_val;  // [nq]
   float* ceil_val;   // [nq]
   int* ceil_idx;     // [nq]
+  float* cand_val;   // [kCandCap][nq]  big-tile scan: candidates behind the prefix floor
+  int* cand_idx;     // [kCandCap][nq]
+  int* cand_cnt;     // [nq] + 1 overflow flag behind it
   size_t bytes;
 };
 
@@ -537,6 +769,9 @@ Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
   w.floor_val = reinterpret_cast<float*>(take((size_t)nq * 4));
   w.ceil_val = reinterpret_cast<float*>(take((size_t)nq * 4));
   w.ceil_idx = reinterpret_cast<int*>(take((size_t)nq * 4));
+  w.cand_val = reinterpret_cast<float*>(take((size_t)kCandCap * nq * 4));
+  w.cand_idx = reinterpret_cast<int*>(take((size_t)kCandCap * nq * 4));
+  w.cand_cnt = reinterpret_cast<int*>(take(((size_t)nq + 1) * 4));
   (void)k;
   w.bytes = off;
   return w;
@@ -569,6 +804,12 @@ void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
   } else {
     launch_scan_cfg<T, 16, 2, 2, 2>(a, grid_x, grid_y, st);
   }
+}
+
+// HCIR_SCAN_BIG=0 keeps the list-keeping scan for every query count (A/B runs)
+inline bool big_scan_enabled() {
+  static const bool on = [] { const char* e = getenv("HCIR_SCAN_BIG"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 void launch_scan_dtype(int dtype, const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
@@ -653,6 +894,56 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     a.row_begin = p.prefix;
     a.row_end = ng;
     a.floor_val = w.floor_val;
+    // Many queries (MFMA-bound): the 256 x 256 tile scan collects the rare rows above the floor; the
+    // list-keeping scan below then only runs (device-side gate) if a candidate buffer overflowed.
+    const bool big = big_scan_enabled() && dtype != HCIR_F32 && nq > 128 && k <= 16 && d % 64 == 0 && !q_inv_norm &&
+                     !g_inv_norm && ng - p.prefix >= 4096;
+    int* overflow = w.cand_cnt + nq;
+    if (big) {
+      if (hipMemsetAsync(w.cand_cnt, 0, ((size_t)nq + 1) * 4, st) != hipSuccess) return HCIR_ERR_LAUNCH;
+      BigScanArgs b{};
+      b.q = q;
+      b.g = g;
+      b.floor_val = w.floor_val;
+      b.cand_val = w.cand_val;
+      b.cand_idx = w.cand_idx;
+      b.cand_cnt = w.cand_cnt;
+      b.overflow = overflow;
+      b.nq = nq;
+      b.row_begin = p.prefix;
+      b.row_end = ng;
+      b.d = d;
+      b.cap = kCandCap;
+      const int64_t qb256 = hcir_cdiv(nq, 256);
+      const int64_t tiles256 = hcir_cdiv(ng - p.prefix, 256);
+      int64_t gx = 256 / qb256;  // one 128 KB workgroup per CU, every query block of a tile run resident
+      gx = gx < 8 ? 8 : (gx & ~int64_t(7));
+      gx = tiles256 < gx ? tiles256 : gx;
+      if (dtype == HCIR_F16)
+        hipLaunchKernelGGL(sim_scan_big_kernel<_Float16>, dim3((unsigned)gx, (unsigned)qb256), dim3(512), 0, st, b);
+      else
+        hipLaunchKernelGGL(sim_scan_big_kernel<__bf16>, dim3((unsigned)gx, (unsigned)qb256), dim3(512), 0, st, b);
+      HCIR_LAUNCH_CHECK();
+      MergeArgs<int> mc{};
+      mc.vals = w.cand_val;
+      mc.idx = w.cand_idx;
+      mc.nq = nq;
+      mc.nlists = kCandCap;
+      mc.nlists_q = w.cand_cnt;
+      mc.kin = 1;
+      mc.kout = k;
+      mc.extra_val = w.pre_val;
+      mc.extra_idx = w.pre_idx;
+      mc.kin_extra = k;
+      mc.out_val = out_val;
+      mc.out_idx = out_idx;
+      mc.idx_base = idx_base;
+      mc.gate = overflow;
+      mc.gate_want = 0;
+      hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, mc);
+      HCIR_LAUNCH_CHECK();
+      a.gate = overflow;  // the launches below: fallback only
+    }
     const int64_t tiles_b = hcir_cdiv(ng - p.prefix, p.gm);
     const int grid_b = scan_grid_x(tiles_b, qblocks);
     launch_scan_dtype(dtype, p, a, grid_b, st);
@@ -670,6 +961,10 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m2.out_val = out_val;
     m2.out_idx = out_idx;
     m2.idx_base = idx_base;
+    if (big) {
+      m2.gate = overflow;
+      m2.gate_want = 1;
+    }
     hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m2);
     HCIR_LAUNCH_CHECK();
     return HCIR_OK;

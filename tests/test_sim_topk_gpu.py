@@ -127,6 +127,49 @@ def test_sim_topk_reduced_precision(ops, dtype, tol, nq, ng, d, k):
     np.testing.assert_allclose(val, rv32, atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nq,ng,d,k", [(129, 70000, 768, 10), (220, 120000, 768, 16), (300, 50000, 128, 16),
+                                       (600, 40000, 64, 1)])
+def test_sim_topk_many_queries_big_tile(ops, dtype, nq, ng, d, k):
+    """nq > 128, k <= 16, fp16/bf16: the 256 x 256 tile scan (candidates above the prefix floor through an
+    atomic append, no register lists).  Scores are bit-identical to the list-keeping kernel (same MFMA chain),
+    which the same gallery reaches with <= 128 queries: compare block by block, values AND indices exactly."""
+    q, g = _rand((nq, d), 21), _rand((ng, d), 22)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    qd, gd = torch.from_numpy(q).cuda().to(dtype), torch.from_numpy(g).cuda().to(dtype)
+    val, idx = ops.sim_topk(qd, gd, k, idx_base=7)
+    for s0 in range(0, nq, 128):          # <= 128 queries: sim_topk_scan with register lists
+        rv, ri = ops.sim_topk(qd[s0:s0 + 128].contiguous(), gd, k, idx_base=7)
+        np.testing.assert_array_equal(idx[s0:s0 + 128].cpu().numpy(), ri.cpu().numpy())
+        np.testing.assert_array_equal(val[s0:s0 + 128].cpu().numpy(), rv.cpu().numpy())
+    # and against float64 scores of the rounded inputs
+    s = qd.float().cpu().numpy().astype(np.float64) @ gd.float().cpu().numpy().astype(np.float64).T
+    rv64, _ = oknn.stable_topk_np(s, k)
+    np.testing.assert_allclose(val.cpu().numpy(), rv64, atol=1e-5, rtol=0)
+
+
+def test_sim_topk_big_tile_overflow_falls_back(ops):
+    """A gallery whose later rows systematically beat its first ones: every row behind the prefix is a
+    near-duplicate of the queries' mean direction, so far more than 512 rows per query clear the prefix floor,
+    the candidate buffers overflow and the device-side gate runs the list-keeping scan.  Same exact result."""
+    rng = np.random.default_rng(31)
+    nq, ng, d, k = 200, 60000, 128, 16
+    base = rng.standard_normal(d).astype(np.float32)
+    q = (base[None] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    g = rng.standard_normal((ng, d)).astype(np.float32)                     # prefix: unrelated rows
+    g[8192:] = base[None] + 0.3 * rng.standard_normal((ng - 8192, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    qd, gd = torch.from_numpy(q).cuda().half(), torch.from_numpy(g).cuda().half()
+    val, idx = ops.sim_topk(qd, gd, k)
+    for s0 in range(0, nq, 100):
+        rv, ri = ops.sim_topk(qd[s0:s0 + 100].contiguous(), gd, k)
+        np.testing.assert_array_equal(idx[s0:s0 + 100].cpu().numpy(), ri.cpu().numpy())
+        np.testing.assert_array_equal(val[s0:s0 + 100].cpu().numpy(), rv.cpu().numpy())
+    assert (idx.cpu().numpy() >= 8192).all()      # the winners really are behind the prefix
+
+
 def test_topk_merge(ops):
     rng = np.random.default_rng(13)
     nl, nq, kin, kout = 8, 50, 10, 10

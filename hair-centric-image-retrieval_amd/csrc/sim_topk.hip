@@ -20,6 +20,7 @@
 //   k > 64 : repeated passes, each taking the next <=64 ranks below a per-query
 //            ceiling (val, idx) left by the previous pass.
 #include "sim_core.h"
+#include <math.h>
 #include <stdlib.h>
 
 #ifndef HCIR_SCAN_AUX
@@ -528,22 +529,27 @@ struct MergeArgs {
   const int* nlists_q;   // optional [nq]: lists of this query = min(nlists_q[q], nlists) (candidate buffers)
   const int* gate;       // optional device flag: run only if (*gate != 0) == (gate_want != 0)
   int gate_want;
+  int* zero_cnt;         // optional [nq + 1]: cleared here (candidate counters + overflow flag of the big scan)
 };
 
-template <typename IdxT>
+template <typename IdxT, int LPL = kMergeLPL>
 __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
   const int lane = threadIdx.x & 63;
   const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= a.nq) return;
   if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  if (a.zero_cnt && lane == 0) {
+    a.zero_cnt[qi] = 0;
+    if (qi == 0) a.zero_cnt[a.nq] = 0;
+  }
   const bool has_extra = a.extra_val != nullptr;
   int nl = a.nlists;
   if (a.nlists_q) nl = a.nlists_q[qi] < nl ? a.nlists_q[qi] : nl;
   const int total = a.nlists + (has_extra ? 1 : 0);
 
-  float cv[kMergeLPL];
-  int64_t ci[kMergeLPL];
-  int hd[kMergeLPL];
+  float cv[LPL];
+  int64_t ci[LPL];
+  int hd[LPL];
   auto fetch = [&](int list, int pos, float& v, int64_t& id) {
     v = kNegInf;
     id = -1;
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
     if (id < 0) v = kNegInf;
   };
 #pragma unroll
-  for (int j = 0; j < kMergeLPL; ++j) {
+  for (int j = 0; j < LPL; ++j) {
     hd[j] = 0;
     fetch(lane + 64 * j, 0, cv[j], ci[j]);
   }
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
     int64_t bi = ci[0];
     int bj = 0;
 #pragma unroll
-    for (int j = 1; j < kMergeLPL; ++j) {
+    for (int j = 1; j < LPL; ++j) {
       const bool take = (ci[j] >= 0) && (bi < 0 || better(cv[j], ci[j], bv, bi));
       bv = take ? cv[j] : bv;
       bi = take ? ci[j] : bi;
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
     }
     if (lane == wl && wi >= 0) {
 #pragma unroll
-      for (int j = 0; j < kMergeLPL; ++j) {
+      for (int j = 0; j < LPL; ++j) {
         if (j == bj) {
           hd[j] += 1;
           fetch(lane + 64 * j, hd[j], cv[j], ci[j]);
@@ -734,9 +740,10 @@ Plan make_plan(int64_t nq, int64_t ng, int k) {
   return p;
 }
 
-// candidates per query the big-tile scan can hold: one-element lists of the final merge, next to the prefix
-// list (kMergeLPL * 64 = 576 lists per pass)
-constexpr int kCandCap = 512;
+// candidates per query the big-tile scan can hold: one-element lists of the final merge (16 per lane), next
+// to the prefix list
+constexpr int kCandLPL = 16;
+constexpr int kCandCap = 64 * kCandLPL - 64;  // 960
 
 struct Workspace {
   float* part_val;
@@ -860,13 +867,31 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   a.d = d;
   a.shared_stream = qblocks > 1 ? 1 : 0;
 
+  Plan pp = p;  // (the prefix may shrink below)
+  // Many queries (MFMA-bound): the 256 x 256 tile scan collects the rare rows above the prefix floor.  The
+  // prefix itself runs on the list-keeping kernel at half that rate, so it is only as long as the candidate
+  // buffers require.  With r = rows behind the prefix / prefix rows, the number of rows that beat the
+  // prefix's k-th score is negative-binomial: mean k r, variance k r (1 + r) ~ (r sqrt k)^2; r is chosen so that
+  // mean + 5 sigma fits the buffer (overflow ~1e-6 per query for a gallery in random order; it is handled).
+  const bool big = big_scan_enabled() && p.npass == 1 && p.prefix < ng && dtype != HCIR_F32 && nq > 128 && k <= 16 &&
+                   d % 64 == 0 && !q_inv_norm && !g_inv_norm && ng - p.prefix >= 4096;
+  if (big) {
+    // (measured flat in r = 8..26 at 220 queries: a shorter prefix is paid back by a longer candidate merge;
+    // r is capped at 15 - the 1/16 prefix of the list-keeping path - which leaves 11 sigma of headroom)
+    int64_t rr = (int64_t)((float)kCandCap / ((float)k + 5.0f * sqrtf((float)k)));
+    rr = rr > 15 ? 15 : rr;
+    int64_t s = hcir_cdiv(ng, (rr < 1 ? 1 : rr) + 1);
+    s = s < 8192 ? 8192 : s;
+    s = hcir_cdiv(s, p.gm) * p.gm;
+    if (s < pp.prefix) pp.prefix = s;
+  }
   if (p.npass == 1) {
     a.k = k;
-    const bool two_phase = p.prefix < ng;
+    const bool two_phase = pp.prefix < ng;
     // phase A: rows [0, prefix)
     a.row_begin = 0;
-    a.row_end = p.prefix;
-    const int64_t tiles_a = hcir_cdiv(p.prefix, p.gm);
+    a.row_end = pp.prefix;
+    const int64_t tiles_a = hcir_cdiv(pp.prefix, p.gm);
     const int grid_a = scan_grid_x(tiles_a, qblocks);
     launch_scan_dtype(dtype, p, a, grid_a, st);
     HCIR_LAUNCH_CHECK();
@@ -888,19 +913,17 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m.out_val = w.pre_val;
     m.out_idx32 = w.pre_idx;
     m.kth_val = w.floor_val;
+    if (big) m.zero_cnt = w.cand_cnt;  // the big scan's counters and overflow flag start at zero
     hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
     HCIR_LAUNCH_CHECK();
     // phase B: rows [prefix, ng) with the prefix k-th score as floor
-    a.row_begin = p.prefix;
+    a.row_begin = pp.prefix;
     a.row_end = ng;
     a.floor_val = w.floor_val;
     // Many queries (MFMA-bound): the 256 x 256 tile scan collects the rare rows above the floor; the
     // list-keeping scan below then only runs (device-side gate) if a candidate buffer overflowed.
-    const bool big = big_scan_enabled() && dtype != HCIR_F32 && nq > 128 && k <= 16 && d % 64 == 0 && !q_inv_norm &&
-                     !g_inv_norm && ng - p.prefix >= 4096;
     int* overflow = w.cand_cnt + nq;
     if (big) {
-      if (hipMemsetAsync(w.cand_cnt, 0, ((size_t)nq + 1) * 4, st) != hipSuccess) return HCIR_ERR_LAUNCH;
       BigScanArgs b{};
       b.q = q;
       b.g = g;
@@ -910,12 +933,12 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       b.cand_cnt = w.cand_cnt;
       b.overflow = overflow;
       b.nq = nq;
-      b.row_begin = p.prefix;
+      b.row_begin = pp.prefix;
       b.row_end = ng;
       b.d = d;
       b.cap = kCandCap;
       const int64_t qb256 = hcir_cdiv(nq, 256);
-      const int64_t tiles256 = hcir_cdiv(ng - p.prefix, 256);
+      const int64_t tiles256 = hcir_cdiv(ng - pp.prefix, 256);
       int64_t gx = 256 / qb256;  // one 128 KB workgroup per CU, every query block of a tile run resident
       gx = gx < 8 ? 8 : (gx & ~int64_t(7));
       gx = tiles256 < gx ? tiles256 : gx;
@@ -940,11 +963,11 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       mc.idx_base = idx_base;
       mc.gate = overflow;
       mc.gate_want = 0;
-      hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, mc);
+      hipLaunchKernelGGL((topk_merge_kernel<int, kCandLPL>), dim3(merge_grid), dim3(256), 0, st, mc);
       HCIR_LAUNCH_CHECK();
       a.gate = overflow;  // the launches below: fallback only
     }
-    const int64_t tiles_b = hcir_cdiv(ng - p.prefix, p.gm);
+    const int64_t tiles_b = hcir_cdiv(ng - pp.prefix, p.gm);
     const int grid_b = scan_grid_x(tiles_b, qblocks);
     launch_scan_dtype(dtype, p, a, grid_b, st);
     HCIR_LAUNCH_CHECK();

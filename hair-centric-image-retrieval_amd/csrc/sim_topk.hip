@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   static_assert(QR * NSRC * KP * 8 <= Cfg::LDS_BYTES, "merge round must fit LDS");
   // LDS-DMA stage ring.  KP = 64 runs one workgroup per CU (128 list registers per lane): a 4-slot ring keeps
   // three stages (108 KB) in flight per CU instead of one; the 2-workgroup configurations keep two slots each.
+  // (A 4-slot ring for the one-tile-per-workgroup prefix launches of the other configurations was measured:
+  // no gain - their ~80 us is not the stage-latency chain.)
   constexpr int NST = (GLDS && KP == 64) ? 4 : 2;
+  static_assert(NST * Cfg::STAGE_BYTES <= 160 * 1024, "stage ring must fit the CU's LDS");
   __shared__ __attribute__((aligned(16))) char lds[NST * Cfg::STAGE_BYTES];
 
   if (a.gate && *a.gate == 0) return;  // uniform: every wave of the grid reads the same flag
@@ -618,6 +621,141 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
   }
 }
 
+// --------------------------------------------------------------------------
+// merge32: the same merge for 32-bit row indices (every intra-GPU merge), latency-tuned.
+//   * a (score, row) pair is ONE 64-bit key: [orderable(score) : ~row]; "better" (score desc, row asc) is the
+//     unsigned maximum, empty slots are key 0;
+//   * the first FOUR entries of each list are fetched up front as two 16-B loads: the k rounds then run from
+//     registers (the old kernel re-fetched the winner's next entry from memory in every round, ~1.5 us each);
+//     a list whose four are used up is refilled in place (rare);
+//   * the wave arg-max is 4 DPP butterfly steps inside each row of 16 lanes + 4 v_readlane + scalar max,
+//     instead of 18 ds_bpermute per round.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t merge_key(float v, int id) {
+  if (id < 0) return 0ull;
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)id);
+}
+__device__ __forceinline__ float merge_key_val(uint64_t k) {
+  uint32_t u = (uint32_t)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ int merge_key_idx(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
+
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_max_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, true);
+  const uint64_t o = ((uint64_t)hi << 32) | lo;
+  return o > v ? o : v;
+}
+// maximum over the 64 lanes, returned wave-uniform
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+  v = dpp_max_u64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max_u64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max_u64<0x141>(v);  // row_half_mirror
+  v = dpp_max_u64<0x140>(v);  // row_mirror: every lane of a 16-lane row now holds the row maximum
+  uint64_t m = 0;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 16 * row);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 16 * row);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    m = o > m ? o : m;
+  }
+  return m;
+}
+
+template <int LPL>
+__global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= a.nq) return;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  if (a.zero_cnt && lane == 0) {
+    a.zero_cnt[qi] = 0;
+    if (qi == 0) a.zero_cnt[a.nq] = 0;
+  }
+  const bool has_extra = a.extra_val != nullptr;
+  int nl = a.nlists;
+  if (a.nlists_q) nl = a.nlists_q[qi] < nl ? a.nlists_q[qi] : nl;
+  const int extra_list = a.nlists;  // list index of the optional extra list
+
+  // entries [pos, pos + 4) of a list as keys (0 where the list has ended)
+  auto fetch4 = [&](int list, int pos, uint64_t (&k4)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k4[e] = 0ull;
+    const float* pv = nullptr;
+    const int* pi = nullptr;
+    int len = 0;
+    if (list < nl) {
+      pv = a.vals + ((int64_t)list * a.nq + qi) * a.kin;
+      pi = a.idx + ((int64_t)list * a.nq + qi) * a.kin;
+      len = a.kin;
+    } else if (has_extra && list == extra_list) {
+      pv = a.extra_val + qi * a.kin_extra;
+      pi = a.extra_idx + qi * a.kin_extra;
+      len = a.kin_extra;
+    }
+    if (pos + 4 <= len && (len & 3) == 0) {  // whole 16-B groups (lists of 16 / 32 / 64 entries)
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pv + pos);
+      const u32x4 id = *reinterpret_cast<const u32x4*>(pi + pos);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) k4[e] = merge_key(v[e], (int)id[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pos + e < len) k4[e] = merge_key(pv[pos + e], pi[pos + e]);
+    }
+  };
+
+  uint64_t kq[LPL][4];
+  int used[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    used[j] = 0;
+    fetch4(lane + 64 * j, 0, kq[j]);
+  }
+  for (int o = 0; o < a.kout; ++o) {
+    uint64_t best = kq[0][0];
+    int bj = 0;
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) {
+      const bool take = kq[j][0] > best;
+      best = take ? kq[j][0] : best;
+      bj = take ? j : bj;
+    }
+    const uint64_t wm = wave_max_u64(best);
+    if (lane == 0) {
+      const bool none = wm == 0ull;
+      const float wv = none ? kNegInf : merge_key_val(wm);
+      const int wi = none ? -1 : merge_key_idx(wm);
+      a.out_val[qi * a.kout + o] = wv;
+      if (a.out_idx) a.out_idx[qi * a.kout + o] = none ? -1 : (int64_t)wi + a.idx_base;
+      if (a.out_idx32) a.out_idx32[qi * a.kout + o] = wi;
+      if (o == a.kout - 1) {
+        if (a.kth_val) a.kth_val[qi] = wv;
+        if (a.kth_idx) a.kth_idx[qi] = wi;
+      }
+    }
+    if (wm != 0ull && best == wm) {  // row indices are unique: exactly one lane and one list hold the winner
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        if (j == bj) {
+          kq[j][0] = kq[j][1];
+          kq[j][1] = kq[j][2];
+          kq[j][2] = kq[j][3];
+          kq[j][3] = 0ull;
+          used[j] += 1;
+          if ((used[j] & 3) == 0) fetch4(lane + 64 * j, used[j], kq[j]);  // its four are used up: refill
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_invnorm_kernel(const T* __restrict__ x, int64_t n, int d,
                                                           int64_t ldx, float eps,
@@ -906,7 +1044,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m.out_val = out_val;
       m.out_idx = out_idx;
       m.idx_base = idx_base;
-      hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
       HCIR_LAUNCH_CHECK();
       return HCIR_OK;
     }
@@ -914,7 +1052,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m.out_idx32 = w.pre_idx;
     m.kth_val = w.floor_val;
     if (big) m.zero_cnt = w.cand_cnt;  // the big scan's counters and overflow flag start at zero
-    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
     HCIR_LAUNCH_CHECK();
     // phase B: rows [prefix, ng) with the prefix k-th score as floor
     a.row_begin = pp.prefix;
@@ -963,7 +1101,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       mc.idx_base = idx_base;
       mc.gate = overflow;
       mc.gate_want = 0;
-      hipLaunchKernelGGL((topk_merge_kernel<int, kCandLPL>), dim3(merge_grid), dim3(256), 0, st, mc);
+      hipLaunchKernelGGL(topk_merge32_kernel<kCandLPL>, dim3(merge_grid), dim3(256), 0, st, mc);
       HCIR_LAUNCH_CHECK();
       a.gate = overflow;  // the launches below: fallback only
     }
@@ -988,7 +1126,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m2.gate = overflow;
       m2.gate_want = 1;
     }
-    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m2);
+    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m2);
     HCIR_LAUNCH_CHECK();
     return HCIR_OK;
   }
@@ -1016,7 +1154,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m.out_idx32 = w.pre_idx;
     m.kth_val = w.ceil_val;
     m.kth_idx = w.ceil_idx;
-    hipLaunchKernelGGL(topk_merge_kernel<int>, dim3(merge_grid), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
     HCIR_LAUNCH_CHECK();
     // scatter this pass's [nq][kk] block into out[:, done:done+kk]
     hipLaunchKernelGGL(pass_copy_kernel, dim3((unsigned)hcir_cdiv(nq * kk, 256)), dim3(256), 0, st,

@@ -58,6 +58,21 @@ __device__ __forceinline__ float topk_kth(const float (&v)[KP], int k) {
   return t;
 }
 
+// (score, row) as ONE 64-bit key: [orderable(score) : ~row]; "better" (score desc, row asc) is the unsigned
+// maximum, an empty slot is key 0.  Used by the in-workgroup and the final merges.
+__device__ __forceinline__ uint64_t merge_key(float v, int id) {
+  if (id < 0) return 0ull;
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)id);
+}
+__device__ __forceinline__ float merge_key_val(uint64_t k) {
+  uint32_t u = (uint32_t)(k >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ int merge_key_idx(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
+
 struct ScanArgs {
   const void* q;
   const void* g;
@@ -287,28 +302,50 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     if (tid < QR && q_row0 + q0r + tid < a.nq) {
       const float* lv = mv + tid * NSRC * KP;
       const int* li = mi + tid * NSRC * KP;
-      unsigned long long heads = 0;  // 8 bits per source
+      // list heads live in registers as 64-bit keys; only the winner's next entry is re-read from LDS
+      // (re-reading all NSRC heads per output through dependent LDS loads took 21 us per workgroup)
+      uint64_t hk[NSRC];
+      int hp[NSRC];
+#pragma unroll
+      for (int s = 0; s < NSRC; ++s) {
+        hp[s] = 0;
+        hk[s] = merge_key(lv[s * KP], li[s * KP]);
+      }
+      // the merged list is collected in registers and stored once, as 16-B pieces: with a store inside the
+      // loop hipcc put `s_waitcnt vmcnt(0)` into every iteration (16 store round trips = 21 us per workgroup)
       float* ov = a.part_val + ((int64_t)blockIdx.x * a.nq + q_row0 + q0r + tid) * KP;
       int* oi = a.part_idx + ((int64_t)blockIdx.x * a.nq + q_row0 + q0r + tid) * KP;
-      for (int o = 0; o < KP; ++o) {
-        float bv = kNegInf;
-        int bi = -1, bs = -1;
+      for (int o0 = 0; o0 < KP; o0 += 16) {  // 16 outputs at a time in registers
+        float ovr[16];
+        int oir[16];
 #pragma unroll
-        for (int s = 0; s < NSRC; ++s) {
-          const int hd = (int)((heads >> (8 * s)) & 0xff);
-          if (hd < KP) {
-            const float v = lv[s * KP + hd];
-            const int id = li[s * KP + hd];
-            if (id >= 0 && (bs < 0 || v > bv || (v == bv && id < bi))) {
-              bv = v;
-              bi = id;
-              bs = s;
+        for (int o = 0; o < 16; ++o) {
+          uint64_t best = hk[0];
+          int bs = 0;
+#pragma unroll
+          for (int s = 1; s < NSRC; ++s) {
+            const bool take = hk[s] > best;
+            best = take ? hk[s] : best;
+            bs = take ? s : bs;
+          }
+          ovr[o] = best ? merge_key_val(best) : kNegInf;
+          oir[o] = best ? merge_key_idx(best) : -1;
+          if (best) {
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) {
+              if (s == bs) {
+                hp[s] += 1;
+                hk[s] = hp[s] < KP ? merge_key(lv[s * KP + hp[s]], li[s * KP + hp[s]]) : 0ull;
+              }
             }
           }
         }
-        ov[o] = bv;
-        oi[o] = bi;
-        if (bs >= 0) heads += 1ull << (8 * bs);
+#pragma unroll
+        for (int o = 0; o < 16; o += 4) {
+          *reinterpret_cast<f32x4*>(ov + o0 + o) = (f32x4){ovr[o], ovr[o + 1], ovr[o + 2], ovr[o + 3]};
+          *reinterpret_cast<u32x4*>(oi + o0 + o) =
+              (u32x4){(uint32_t)oir[o], (uint32_t)oir[o + 1], (uint32_t)oir[o + 2], (uint32_t)oir[o + 3]};
+        }
       }
     }
     __syncthreads();
@@ -631,19 +668,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
 //   * the wave arg-max is 4 DPP butterfly steps inside each row of 16 lanes + 4 v_readlane + scalar max,
 //     instead of 18 ds_bpermute per round.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t merge_key(float v, int id) {
-  if (id < 0) return 0ull;
-  uint32_t u = __builtin_bit_cast(uint32_t, v);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)id);
-}
-__device__ __forceinline__ float merge_key_val(uint64_t k) {
-  uint32_t u = (uint32_t)(k >> 32);
-  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-  return __builtin_bit_cast(float, u);
-}
-__device__ __forceinline__ int merge_key_idx(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
-
 template <int CTRL>
 __device__ __forceinline__ uint64_t dpp_max_u64(uint64_t v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, true);

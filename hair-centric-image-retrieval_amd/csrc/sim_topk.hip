@@ -330,14 +330,19 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
           }
           ovr[o] = best ? merge_key_val(best) : kNegInf;
           oir[o] = best ? merge_key_idx(best) : -1;
-          if (best) {
+          // advance the winner's list: ONE LDS read pair at a per-lane address, then select-chain updates
+          // (a branch per source serialised eight LDS round trips per output across the divergent lanes)
+          int np = 0;
 #pragma unroll
-            for (int s = 0; s < NSRC; ++s) {
-              if (s == bs) {
-                hp[s] += 1;
-                hk[s] = hp[s] < KP ? merge_key(lv[s * KP + hp[s]], li[s * KP + hp[s]]) : 0ull;
-              }
-            }
+          for (int s = 0; s < NSRC; ++s) np = (s == bs) ? hp[s] + 1 : np;
+          const bool more = best != 0ull && np < KP;
+          const int at = bs * KP + (more ? np : 0);
+          const uint64_t nk = more ? merge_key(lv[at], li[at]) : 0ull;
+#pragma unroll
+          for (int s = 0; s < NSRC; ++s) {
+            const bool upd = best != 0ull && s == bs;
+            hp[s] = upd ? np : hp[s];
+            hk[s] = upd ? nk : hk[s];
           }
         }
 #pragma unroll

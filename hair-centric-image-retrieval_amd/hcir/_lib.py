@@ -59,6 +59,7 @@ SIGNATURES = {
     "hcir_cls_head": (c_int, [c_vp, c_int, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_int, c_vp, c_vp, c_vp]),
     "hcir_patch_mean": (c_int, [c_vp, c_int, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "hcir_knn_transform_u8": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "hcir_ema_update": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
     "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
 }
 

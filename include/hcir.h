@@ -247,6 +247,15 @@ int hcir_patch_mean(const void* tok, int tok_dtype, int64_t b, int32_t t, int32_
 int hcir_knn_transform_u8(const uint8_t* img, int64_t b, int32_t h, int32_t w, int32_t size,
                           const float* mean3, const float* std3, float* out, void* stream);
 
+/* EMA update of the momentum encoder, every parameter tensor in ONE launch:
+ *     ema = ema * m + p * one_minus_m        (fp32, two rounded multiplies + one rounded add: bit-exact with
+ *                                             lightly's update_momentum, HP/src/pretrain_engine.py:618-619)
+ * dst_ptrs / src_ptrs / counts are DEVICE arrays of n_chunks entries: chunk c covers counts[c] consecutive
+ * floats at address dst_ptrs[c] (ema) and src_ptrs[c] (online parameters).  The caller builds the table once
+ * per model pair (hcir.momentum) and splits big tensors into chunks of its choice. */
+int hcir_ema_update(const uint64_t* dst_ptrs, const uint64_t* src_ptrs, const int64_t* counts,
+                    int64_t n_chunks, float m, float one_minus_m, void* stream);
+
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 

@@ -421,3 +421,39 @@ def test_knn_transform_u8_goldens_and_errors(golden_dir):
         knn_transform_u8(torch.zeros(1, 224, 224, 3, dtype=torch.uint8))          # CPU tensor: no fallback
     with pytest.raises(HcirError):
         knn_transform_u8(torch.zeros(1, 224, 224, 3, device="cuda"))               # not uint8
+
+
+# ------------------------------------------------------------------ momentum encoder update (pretrain step)
+def test_update_momentum_bit_exact():
+    """hcir.momentum.update_momentum == lightly's `ema.data = ema.data * m + p.data * (1.0 - m)` bit for bit,
+    over every parameter of SHAM2's backbone + projection head in one launch; the engine cache sees the update."""
+    from hcir import HcirError
+    from hcir.main_backbone import SHAM2
+    from hcir.momentum import update_momentum
+    torch.manual_seed(50)
+    model = SHAM2("vit_b_16").cuda()
+    _randomize(model, 51)
+    with torch.no_grad():
+        for p in model.backbone_momentum.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    for m in (0.99, 0.996, 0.5):
+        want = [e.data * m + p.data * (1.0 - m)
+                for p, e in zip(model.backbone.parameters(), model.backbone_momentum.parameters())]
+        vers = [e._version for e in model.backbone_momentum.parameters()]
+        update_momentum(model.backbone, model.backbone_momentum, m)
+        update_momentum(model.projection_head, model.projection_head_momentum, m)
+        torch.cuda.synchronize()
+        for e, w, v in zip(model.backbone_momentum.parameters(), want, vers):
+            assert torch.equal(e.data, w)
+            assert e._version > v
+    # the momentum forward runs on the updated weights
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        a = model.extract_features_ema(x)
+        update_momentum(model.backbone, model.backbone_momentum, 0.0)      # ema := online weights
+        b = model.extract_features_ema(x)
+        c = model.extract_features(x)
+    assert not torch.equal(a, b)
+    assert _cos_err(b, c) <= 1e-6
+    with pytest.raises(HcirError):
+        update_momentum(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), 0.9)    # CPU parameters: no fallback

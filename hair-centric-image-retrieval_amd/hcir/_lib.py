@@ -60,6 +60,8 @@ SIGNATURES = {
     "hcir_patch_mean": (c_int, [c_vp, c_int, c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "hcir_knn_transform_u8": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "hcir_ema_update": (c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp]),
+    "hcir_positive_masking": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp]),
     "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
 }
 

@@ -65,3 +65,50 @@ def center_window_u8(image, size: int = 224) -> torch.Tensor:
         h, w = arr.shape[:2]
     top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
     return torch.from_numpy(np.ascontiguousarray(arr[top:top + size, left:left + size]))
+
+
+class PositiveMaskingTransform:
+    """HP/utils/transform.py:84-150 on the HIP device (hcir_positive_masking): same constructor and call,
+    no per-image host round trip.  `__call__(images, generator=None)` draws the per-image mask ratio and one
+    key per patch with torch's generator on the device (the reference's uniform_ + randperm), or takes them
+    explicitly through `apply(images, u, keys)` — which is what the parity tests drive."""
+
+    def __init__(self, patch_size=32, mask_ratio_range=(0.1, 0.2), threshold=0.01):
+        self.patch_size = patch_size
+        self.mask_ratio_range = mask_ratio_range
+        self.threshold = threshold
+
+    def apply(self, images: torch.Tensor, u: torch.Tensor, keys: torch.Tensor, return_counts: bool = False):
+        from . import _lib
+        from ._lib import HcirError, check
+        if not isinstance(images, torch.Tensor):
+            raise ValueError("Input must be a torch.Tensor")
+        if not images.is_cuda:
+            raise HcirError(f"images are on {images.device}; PositiveMaskingTransform runs on a HIP device only")
+        if images.dim() != 4:
+            raise HcirError(f"expected [B, C, H, W], got {tuple(images.shape)}")
+        x = images.float().contiguous()
+        b, c, h, w = x.shape
+        p = int(self.patch_size)
+        npatch = (h // p) * (w // p)
+        u = u.to(device=x.device, dtype=torch.float32).contiguous()
+        keys = keys.to(device=x.device, dtype=torch.float32).contiguous()
+        if u.numel() != b or keys.numel() != b * npatch:
+            raise HcirError("u must have B entries and keys B * (H/patch) * (W/patch)")
+        out = torch.empty_like(x)
+        cnt = torch.empty(b, dtype=torch.int32, device=x.device)
+        check(_lib.lib().hcir_positive_masking(x.data_ptr(), b, c, h, w, p, float(self.threshold), u.data_ptr(),
+                                               keys.data_ptr(), out.data_ptr(), cnt.data_ptr(),
+                                               torch.cuda.current_stream(x.device).cuda_stream),
+              "hcir_positive_masking")
+        return (out, cnt) if return_counts else out
+
+    def __call__(self, images: torch.Tensor, generator=None) -> torch.Tensor:
+        if not isinstance(images, torch.Tensor):
+            raise ValueError("Input must be a torch.Tensor")
+        b, _, h, w = images.shape
+        npatch = (h // self.patch_size) * (w // self.patch_size)
+        lo, hi = self.mask_ratio_range
+        u = torch.empty(b, device=images.device).uniform_(lo, hi, generator=generator)
+        keys = torch.rand((b, npatch), device=images.device, generator=generator)
+        return self.apply(images, u, keys)

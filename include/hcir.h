@@ -256,6 +256,17 @@ int hcir_knn_transform_u8(const uint8_t* img, int64_t b, int32_t h, int32_t w, i
 int hcir_ema_update(const uint64_t* dst_ptrs, const uint64_t* src_ptrs, const int64_t* counts,
                     int64_t n_chunks, float m, float one_minus_m, void* stream);
 
+/* PositiveMaskingTransform on the device (HP/utils/transform.py:84-150; the masked positive view of the
+ * pretrain step, HP/src/pretrain_engine.py:692-694).  images/out fp32 [B][C][H][W] (may not alias).  A patch
+ * (patch x patch, non-overlapping grid) is a "hair" patch when its mean over (C, patch, patch) > threshold;
+ * per image int(n_hair * u[b]) hair patches — those with the smallest keys[b][patch] (ties: smaller patch
+ * index) — are zeroed.  u [B] and keys [B][(H/patch)*(W/patch)] are DEVICE arrays of the caller's random
+ * numbers (u ~ U(mask_ratio_range), keys ~ U(0,1): the reference's uniform_ + randperm as data).
+ * n_masked [B] (optional) receives the number of zeroed patches. */
+int hcir_positive_masking(const float* images, int64_t b, int32_t c, int32_t h, int32_t w, int32_t patch,
+                          float threshold, const float* u, const float* keys, float* out,
+                          int32_t* n_masked, void* stream);
+
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 

@@ -38,3 +38,33 @@ def grid_windows(pil_image, n: int, size: int = 224):
             if len(out) < n:
                 out.append(window_to_tensor(img[y:y + size, x:x + size]))
     return np.stack(out)
+
+
+def positive_masking(images: np.ndarray, u: np.ndarray, keys: np.ndarray, patch_size: int = 32,
+                     threshold: float = 0.01):
+    """PositiveMaskingTransform.__call__ (HP/utils/transform.py:101-150) restated as the same per-image loop,
+    with its randomness as data: u[b] is the mask ratio the reference draws with uniform_ (:133), and the random
+    subset it takes with randperm (:139) is the `num_mask` hair patches with the smallest keys[b] (ties: smaller
+    patch index).  images float32 [B, C, H, W].  Returns (masked images, number of zeroed patches per image)."""
+    B, C, H, W = images.shape
+    nh, nw = H // patch_size, W // patch_size
+    out = images.copy()
+    counts = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        means = np.zeros(nh * nw, dtype=np.float64)
+        for ph in range(nh):
+            for pw in range(nw):
+                blk = images[b, :, ph * patch_size:(ph + 1) * patch_size, pw * patch_size:(pw + 1) * patch_size]
+                means[ph * nw + pw] = blk.astype(np.float64).mean()            # :124 mean over (C, ph, pw)
+        hair = np.nonzero(means > threshold)[0]                               # :125,130
+        if len(hair) == 0:
+            continue
+        num_mask = int(len(hair) * float(u[b]))                               # :134-135
+        if num_mask == 0:
+            continue
+        order = sorted(hair, key=lambda i: (float(keys[b, i]), i))
+        for idx in order[:num_mask]:                                          # :142-146
+            ph, pw = idx // nw, idx % nw
+            out[b, :, ph * patch_size:(ph + 1) * patch_size, pw * patch_size:(pw + 1) * patch_size] = 0.0
+        counts[b] = num_mask
+    return out, counts

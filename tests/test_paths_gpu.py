@@ -457,3 +457,37 @@ def test_update_momentum_bit_exact():
     assert _cos_err(b, c) <= 1e-6
     with pytest.raises(HcirError):
         update_momentum(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), 0.9)    # CPU parameters: no fallback
+
+
+# ------------------------------------------------------------------ PositiveMaskingTransform (pretrain step)
+@pytest.mark.parametrize("b,h,w,patch", [(6, 224, 224, 32), (3, 224, 224, 16), (2, 100, 130, 32)])
+def test_positive_masking_vs_oracle(b, h, w, patch):
+    """hcir_positive_masking == the reference's per-image loop driven by the same random numbers: identical
+    masked images and counts.  Images are hair-on-black composites (patch means far from the 0.01 threshold)."""
+    from hcir.transform import PositiveMaskingTransform
+    rng = np.random.default_rng(b * 100 + patch)
+    img = rng.uniform(0.2, 1.0, size=(b, 3, h, w)).astype(np.float32)
+    nh, nw = h // patch, w // patch
+    for i in range(b):                                  # black out a random ~40 % of the patches
+        dead = rng.random((nh, nw)) < 0.4
+        for ph in range(nh):
+            for pw in range(nw):
+                if dead[ph, pw]:
+                    img[i, :, ph * patch:(ph + 1) * patch, pw * patch:(pw + 1) * patch] = 0.0
+    img[b - 1] = 0.0                                    # an image with no hair at all is returned unchanged
+    u = rng.uniform(0.1, 0.2, size=b).astype(np.float32)
+    u[0] = 0.0009                                       # int(n_hair * u) == 0: nothing masked
+    keys = rng.random((b, nh * nw)).astype(np.float32)
+    keys[1, :4] = keys[1, 5]                            # ties between keys resolve by patch index
+    t = PositiveMaskingTransform(patch_size=patch, mask_ratio_range=(0.1, 0.2), threshold=0.01)
+    got, cnt = t.apply(torch.from_numpy(img).cuda(), torch.from_numpy(u), torch.from_numpy(keys), return_counts=True)
+    ref, rcnt = otf.positive_masking(img, u, keys, patch_size=patch, threshold=0.01)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert rcnt[0] == 0 and rcnt[b - 1] == 0 and (b <= 2 or rcnt[1:b - 1].min() >= 1)
+    # the drawing form: same contract as the reference's __call__ (10-20 % of the hair patches zeroed)
+    out = t(torch.from_numpy(img).cuda(), generator=torch.Generator(device="cuda").manual_seed(3))
+    zeroed = ((out == 0).all(dim=1) & (torch.from_numpy(img).cuda() != 0).any(dim=1)).float().sum().item()
+    assert b <= 2 or zeroed > 0
+    with pytest.raises(ValueError):
+        t([1, 2, 3])

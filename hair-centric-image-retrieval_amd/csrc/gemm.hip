@@ -5,12 +5,13 @@
 // HP/src/main_backbone.py:554) and Conv2d(3,768,16,16) patch embedding
 // (HP/src/main_backbone.py:543; HP/src/models_vit.py:42,48).
 //
-// Tile engine: sim_core.h with W rows on the MFMA row index and activation rows on
-// the MFMA column index: a lane owns ONE activation row m and receives the output
-// features n in groups of 4 consecutive registers, so the epilogue reads/writes
-// 8 B (fp16) or 16 B (fp32) per lane per group.  Workgroup tile 128(n) x 128(m) x 64(k),
-// 4 waves as 2(n) x 2(m), each wave 2x2 MFMA 32x32x16 tiles, LDS double buffer,
-// global loads register-staged one k-chunk ahead.
+// Two kernels (launch_gemm picks):
+//   * gemm_f16_big_kernel — M >= 1024, N % 256 == 0, K % 64 == 0 (every encoder GEMM of the benchmark):
+//     persistent 256(n) x 256(m) x 64(k) tiles, 8 waves of 128 x 64 (MFMA 16x16x32), two 64 KB LDS slots filled
+//     by LDS-DMA, LDS-transposed full-line epilogues incl. the LayerNorm fold (hcir_gemm_f16_fused);
+//   * gemm_f16_kernel — everything else (small M, ragged N / K): the sim_core.h tile engine with W rows on the
+//     MFMA row index and activation rows on the column index (a lane owns ONE activation row and receives the
+//     output features in groups of 4 registers), workgroup tile 128 x 128 x 64, 4 waves of 2x2 MFMA 32x32x16.
 #include "sim_core.h"
 #include <stdlib.h>
 
@@ -148,12 +149,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
                                               int64_t m0, int n0, int wave_n, int wave_m, int lane) {
   gemm_epilogue_t<EPI, 2>(g, acc, m0, n0 + wave_n * 64, wave_m, lane);
 }
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue256(const GemmArgs& g, const f32x16 (&acc)[4][2],
-                                                 int64_t m0, int nbase, int wave_m, int lane) {
-  gemm_epilogue_t<EPI, 4>(g, acc, m0, nbase, wave_m, lane);
-}
-
 // Hide a value's origin from hipcc's waitcnt pass: after the explicit wait below, bias / scale
 // registers are "produced by asm", not by a pending global load.  Without this the per-iteration
 // control flow of the store loop makes the pass re-insert `s_waitcnt vmcnt(0)` before EVERY store

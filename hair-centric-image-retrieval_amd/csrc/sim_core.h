@@ -55,17 +55,6 @@ struct SimCfg {
   static_assert((ROWS * 8) % 256 == 0, "slot count must divide evenly");
 };
 
-// 8-wave configuration for the big GEMM tile: 2 x 4 waves, each 2x2 MFMA tiles:
-// 128 stream rows (W) x 256 resident rows (activations), 48 KB per stage.
-struct SimCfgBig {
-  static constexpr int NT = 512;
-  static constexpr int GM = 128;
-  static constexpr int QB = 256;
-  static constexpr int ROWS = GM + QB;
-  static constexpr int NLOAD = ROWS * 8 / NT;  // 6
-  static constexpr int STAGE_BYTES = ROWS * 128;
-};
-
 __device__ __forceinline__ int sim_slot_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }

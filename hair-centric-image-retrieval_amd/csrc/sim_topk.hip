@@ -19,6 +19,10 @@
 //            a smaller index and wins the tie).
 //   k > 64 : repeated passes, each taking the next <=64 ranks below a per-query
 //            ceiling (val, idx) left by the previous pass.
+//   > 128 queries (k <= 16, fp16/bf16): the rows behind the prefix go through
+//            sim_scan_big_kernel - the GEMM's 256 x 256 tile, no lists: the rare rows above
+//            the floor are appended to per-query candidate buffers; a device flag gates the
+//            list-keeping scan as fallback if a buffer overflows.
 #include "sim_core.h"
 #include <math.h>
 #include <stdlib.h>

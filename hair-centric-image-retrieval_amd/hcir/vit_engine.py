@@ -5,8 +5,9 @@ A `VitSpec` is the architecture-neutral description both model families
 `VitEngine.forward_tokens` runs
     patch_embed (+cls, +pos)  ->  depth x [ LN -> qkv GEMM -> fused attention ->
     proj GEMM (+residual) -> LN -> fc1 GEMM (+GELU) -> fc2 GEMM (+residual) ]
-with fp16 MFMA operands, fp32 accumulation and an fp32 residual stream, entirely in
-device buffers the engine owns (re-used across calls).  There is no CPU path.
+with fp16 MFMA operands, fp32 accumulation and an fp32 or fp16 residual stream, entirely in
+device buffers the engine owns (re-used across calls).  With the fp16 stream and >= 1024 token rows
+the LayerNorms are folded into the neighbouring GEMMs (hcir_gemm_f16_fused).  There is no CPU path.
 """
 from __future__ import annotations
 

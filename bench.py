@@ -189,9 +189,9 @@ def main():
     # finished (certified, fallback, cross-rank merge) inside the timed region.
     pending = [None]
 
-    def step(prof=None):
+    def step(prof=None, xin=None):
         with torch.no_grad():
-            e32, e16 = vit.forward_cls(x, l2_normalize=True, want_f16=True)
+            e32, e16 = vit.forward_cls(x if xin is None else xin, l2_normalize=True, want_f16=True)
             if prof:
                 prof.mark("cls_head")
             q = e32 if gdtype == torch.float32 else e16
@@ -271,6 +271,53 @@ def main():
         sim64_ms = ev[2].elapsed_time(ev[3]) / 5
         scan_esize = scan_g.element_size()
 
+    # ---- PCIe-inclusive rate (NOT `value`): the same step fed from pinned host memory, the copy of batch i+1 on a
+    # side stream under the compute of batch i (two device buffers).  "f32": pre-normalised fp32 crops, the input
+    # contract of SURVEY.md §8d (132 MB per batch); "u8": RGB8 centre windows (33 MB) + hcir_knn_transform_u8.
+    def pcie_rate(kind, n=8):
+        from hcir.transform import knn_transform_u8
+        shape, dt = ((args.batch, 3, 224, 224), torch.float32) if kind == "f32" else ((args.batch, 224, 224, 3), torch.uint8)
+        host = [torch.empty(shape, dtype=dt).pin_memory() for _ in range(2)]
+        for hb in host:
+            if kind == "f32":
+                hb.normal_()
+            else:
+                hb.random_(0, 256)
+        devb = [torch.empty(shape, dtype=dt, device=dev) for _ in range(2)]
+        cs = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event() for _ in range(2)]
+        consumed = [torch.cuda.Event() for _ in range(2)]
+        main = torch.cuda.current_stream(dev)
+
+        def run(count):
+            for i in range(count + 1):
+                if i < count:
+                    with torch.cuda.stream(cs):
+                        if i >= 2:
+                            cs.wait_event(consumed[i % 2])
+                        devb[i % 2].copy_(host[i % 2], non_blocking=True)
+                        copied[i % 2].record(cs)
+                if i >= 1:
+                    j = (i - 1) % 2
+                    main.wait_event(copied[j])
+                    xin = devb[j] if kind == "f32" else knn_transform_u8(devb[j])
+                    step(xin=xin)
+                    consumed[j].record(main)
+            drain()
+
+        run(2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        return args.batch * n / (time.perf_counter() - t1)
+
+    pcie = None
+    if world == 1:
+        pcie = {"note": "same step, inputs copied from pinned host memory on a side stream under the previous "
+                        "batch's compute; not `value`",
+                "f32_crops_img_per_s": pcie_rate("f32"), "u8_windows_device_transform_img_per_s": pcie_rate("u8")}
+
     if rank == 0:
         # HBM-side traffic of the dominant kernel: PMC counters cannot be read from inside this
         # process; the committed summary of the separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`
@@ -326,6 +373,7 @@ def main():
                               "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                               "frac": (attn_f / (attn_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF) if attn_ms else 0.0},
             "phase_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+            "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd_cpu, host_cores())

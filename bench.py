@@ -328,6 +328,12 @@ def main():
                 gemm_traffic = json.load(f).get("gemm_f16_big_kernel_avg_bytes_per_launch")
         except (OSError, ValueError):
             pass
+        scan_traffic = None  # whole 64-query call (prefix + main scan), same PMC recipe, tools/scan_point.py
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_final_pmc_scan.json")) as f:
+                scan_traffic = json.load(f).get("whole_call_bytes")
+        except (OSError, ValueError):
+            pass
         total_imgs = args.batch * world * args.steps
         gemm_f, attn_f, patch_f = vit_flops(args.batch)
         gemm_ms = sum(per_step.get(k, 0.0) for k in gemm_f)
@@ -365,6 +371,7 @@ def main():
                                   "mfma_frac": sim_tf / (MFMA_F32_PEAK_TF if scan_esize == 4 else MFMA_F16_PEAK_TF),
                                   "streaming_64_queries": {"ms": sim64_ms, "achieved": sim64_gbs,
                                                            "frac": sim64_gbs / HBM_PEAK_GBS,
+                                                           "traffic": scan_traffic if (args.gallery == 1_000_000 and world == 1 and scan_esize == 2) else None,
                                                            "note": "same kernel + merges at its HBM-bound design "
                                                                    "point (64 queries); not part of `value`"},
                                   "filter_stats": None if resident is None else dict(resident.stats)},

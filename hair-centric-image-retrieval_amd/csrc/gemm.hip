@@ -223,38 +223,40 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
         scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
     }
   }
-  // LayerNorm fold, out = rstd[m] acc + (-rstd[m] mean[m]) c1[n] + bias[n], all on the row side: the fp16
-  // image holds the raw accumulators (same relative rounding as a pre-scaled image; |acc| stays far below
-  // the fp16 range: it is a 768..4096-term dot product of fp16 residual values with LayerNorm-scaled weights),
-  // then x = rstd[row] * v + (u[row] * c1[n] + bias[n]) with u = -rstd * mean for the 8 rows this lane stores.
-  float ln_rs[8], ln_u[8];
-  f32x4 c1r[NPASS][NB];
+  // LayerNorm fold, out = rstd[m] (acc - mean[m] c1[n]) + bias[n].  The CENTERING runs on the accumulator side,
+  // in fp32, before the fp16 image: rounding the raw accumulator first loses the result under the cancellation
+  // acc - mean c1 when |mean| >> std (measured: 20x the error at mean/std = 50, 2.4x at 5; equal at 0).  The
+  // scaling by rstd[row] and the bias run on the row side.
+  //   accumulator layout: mean of the 4 (2) rows this lane owns there, c1 of its features there
+  //   (16x16x32: n = 16 t + 4 (lane>>4) + e, t < 8;  32x32x16: n = 32 nt + 8 grp + 4 h + e)
+  float ln_rs[8], ln_mean[4];
+  f32x4 c1a[MF16 ? 8 : 16];
   if constexpr (kLn) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       int64_t mm = m0w + it * 8 + rrow;
       mm = mm < g.m ? mm : g.m - 1;
-      const f32x2 ms = *reinterpret_cast<const f32x2*>(g.ln_stats + 2 * mm);
-      ln_rs[it] = ms[1];
-      ln_u[it] = -ms[0] * ms[1];
+      ln_rs[it] = g.ln_stats[2 * mm + 1];
     }
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass)
+    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) {
+      int64_t mm = m0w + (MF16 ? 16 * mt + (lane & 15) : 32 * mt + r);
+      mm = mm < g.m ? mm : g.m - 1;
+      ln_mean[mt] = g.ln_stats[2 * mm];
+    }
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        c1r[pass][j] = *reinterpret_cast<const f32x4*>(g.ln_c1 + nbase + pass * 64 + rchunk * 8 + 4 * j);
+    for (int t = 0; t < (MF16 ? 8 : 16); ++t)
+      c1a[t] = *reinterpret_cast<const f32x4*>(
+          g.ln_c1 + nbase + (MF16 ? 16 * t + 4 * (lane >> 4) : 32 * (t >> 2) + 8 * (t & 3) + 4 * h));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (kLn) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      asm volatile("" : "+v"(ln_rs[it]));
-      asm volatile("" : "+v"(ln_u[it]));
-    }
+    for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(ln_rs[it]));
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass)
+    for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) asm volatile("" : "+v"(ln_mean[mt]));
 #pragma unroll
-      for (int j = 0; j < NB; ++j) launder(c1r[pass][j]);
+    for (int t = 0; t < (MF16 ? 8 : 16); ++t) launder(c1a[t]);
   }
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass)
@@ -278,8 +280,14 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
               f16x4 o;
+              if constexpr (kLn) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
+                for (int e = 0; e < 4; ++e)
+                  o[e] = (_Float16)__builtin_fmaf(-ln_mean[mt], c1a[4 * nt + grp][e], acc.a[nt][mt][4 * grp + e]);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][4 * grp + e];
+              }
               const int chunk = q * 4 + grp;
               *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * h) = o;
             }
@@ -305,8 +313,13 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           for (int q = 0; q < 4; ++q) {   // 64 features per pass = 4 n-tiles of 16
             const int nt = 4 * pass + q;
             f16x4 o;
+            if constexpr (kLn) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)__builtin_fmaf(-ln_mean[mt], c1a[nt][e], acc.a[nt][mt][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+            }
             const int chunk = 2 * q + (q16 >> 1);
             *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
           }
@@ -352,7 +365,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
             } else if constexpr (kResidH) {
               x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
             } else if constexpr (kLn) {
-              x = __builtin_fmaf(ln_rs[it0 + u], x, __builtin_fmaf(ln_u[it0 + u], c1r[pass][e >> 2][e & 3], bb));
+              x = __builtin_fmaf(ln_rs[it0 + u], x, bb);
             } else {
               x += bb;
             }
@@ -437,6 +450,9 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 template <int EPI, bool MF16>
 __device__ __forceinline__ void gemm_epilogue256_lds(const GemmArgs& g, const WaveAcc<MF16>& acc,
                                                      char* region, int64_t m0w, int nbase, int lane) {
+  // opaque lane id: the epilogue's ~60 loop-invariant LDS / global addresses all derive from it, so hipcc
+  // cannot hoist them out of the persistent tile loop into long-lived registers
+  asm volatile("" : "+v"(lane));
   if (m0w + 64 <= g.m)
     gemm_epilogue256_lds_impl<EPI, true, MF16>(g, acc, region, m0w, nbase, lane);
   else

@@ -387,3 +387,47 @@ def test_vit_requires_no_grad_and_device(L):
         model.extract_features(x.cuda())  # autograd on: backward is not built
     with pytest.raises(ValueError):
         SHAM2("vgg16")
+
+
+@pytest.mark.parametrize("mean_over_std,outlier", [(0.0, 0.0), (5.0, 0.0), (50.0, 0.0), (1.0, 300.0)])
+def test_layernorm_fold_precision_under_offsets(L, mean_over_std, outlier):
+    """The folded form computes rstd * (x . W'^T) - rstd * mean * c1: with a large row mean the two terms cancel.
+    Rows with mean/std up to 50 and a 300-sigma outlier channel (the "massive activation" pattern of trained
+    ViTs): the folded GEMM must stay as close to the fp32 LayerNorm + Linear as the separate
+    hcir_layernorm_f16 + hcir_gemm_f16 path does (both are limited by one fp16 rounding of an operand)."""
+    g = torch.Generator().manual_seed(int(mean_over_std * 10 + outlier))
+    m, d, n, eps = 1280, 768, 768, 1e-6
+    x = torch.randn(m, d, generator=g) + mean_over_std * (1.0 + 0.1 * torch.randn(m, 1, generator=g))
+    if outlier:
+        x[:, 7] += outlier
+    x16 = x.half()
+    gamma = 1.0 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.2 * torch.randn(d, generator=g)
+    w = torch.randn(n, d, generator=g) * d ** -0.5
+    b = torch.randn(n, generator=g)
+    ref = (F.layer_norm(x16.double(), (d,), gamma.double(), beta.double(), eps) @ w.double().t() + b.double()).float()
+    xd = x16.cuda()
+    # separate path
+    ln = torch.empty((m, d), dtype=torch.float16, device="cuda")
+    out_sep = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    assert L.hcir_layernorm_f16(xd.data_ptr(), 1, m, d, d, gamma.cuda().data_ptr(), beta.cuda().data_ptr(), eps,
+                                ln.data_ptr(), d, _st()) == 0
+    w16 = w.half().cuda()
+    assert L.hcir_gemm_f16(ln.data_ptr(), d, w16.data_ptr(), d, b.cuda().data_ptr(), None, m, n, d, 0,
+                           out_sep.data_ptr(), n, _st()) == 0
+    # folded path: statistics of the stored rows, W' = fp16(gamma o W)
+    xs = x16.double()
+    stats = torch.stack([xs.mean(1), (xs.var(1, unbiased=False) + eps).rsqrt()], 1).float().cuda()
+    wg = (w.double() * gamma.double()[None, :]).half()
+    c1 = wg.double().sum(1).float().cuda()
+    c2 = (w.double() @ beta.double() + b.double()).float().cuda()
+    out_fold = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    assert L.hcir_gemm_f16_fused(xd.data_ptr(), d, wg.cuda().data_ptr(), d, c2.data_ptr(), None, m, n, d, 0,
+                                 out_fold.data_ptr(), n, stats.data_ptr(), c1.data_ptr(), None, _st()) == 0
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    e_sep = (out_sep.float().cpu() - ref).abs().max().item() / scale
+    e_fold = (out_fold.float().cpu() - ref).abs().max().item() / scale
+    print(f"mean/std {mean_over_std}, outlier {outlier}: max err / max|ref|  separate {e_sep:.2e}  folded {e_fold:.2e}")
+    assert e_sep <= 4e-3
+    assert e_fold <= max(4e-3, 3.0 * e_sep)

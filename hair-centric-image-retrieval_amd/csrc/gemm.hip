@@ -384,19 +384,27 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           const int64_t m = m0w + row;
           if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
           if constexpr (EPI == EPI_RESID_F16_STATS) {
-            // (sum, sum of squares) of the 64 STORED fp16 values of this row slice, for the next LayerNorm
-            float s1 = 0.f, s2 = 0.f;
+            // (mean, sum of squared deviations from that mean) of the 64 STORED fp16 values of this row slice,
+            // for the next LayerNorm.  Two-pass per slice (the values are in registers) and Chan's combination
+            // in the finalize kernel: a plain (sum, sum of squares) pair loses the variance to cancellation
+            // when |mean| >> std (0.2 % error in rstd at mean/std = 50).
+            float xv[8], s1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float xv = (float)o[e];
-              s1 += xv;
-              s2 = __builtin_fmaf(xv, xv, s2);
+              xv[e] = (float)o[e];
+              s1 += xv[e];
             }
-            s1 = sum8_dpp(s1);
-            s2 = sum8_dpp(s2);
+            const float mean_s = sum8_dpp(s1) * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float dv = xv[e] - mean_s;
+              m2 = __builtin_fmaf(dv, dv, m2);
+            }
+            m2 = sum8_dpp(m2);
             if (rchunk == 0 && (FULL || m < g.m)) {
               const int64_t slice = (nbase >> 6) + pass;
-              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){s1, s2};
+              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){mean_s, m2};
             }
           }
         }
@@ -843,19 +851,22 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
 }
 
-// (sum, sumsq) slices of hcir_gemm_f16_fused -> (mean, rstd) per row; slices are added in index order
-__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, int64_t m, float inv_n,
+// (mean, M2) of the 64-feature slices of hcir_gemm_f16_fused -> (mean, rstd) per row by Chan's parallel-variance
+// combination (equal slice sizes), slices visited in index order: deterministic, no cancellation
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int parts, int64_t m, float slice_n,
                                          float eps, float* __restrict__ stats) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
-  float s1 = 0.f, s2 = 0.f;
+  float ms = 0.f;
+  for (int p = 0; p < parts; ++p) ms += part[((int64_t)p * m + row) * 2];
+  const float mean = ms / (float)parts;
+  float m2 = 0.f;
   for (int p = 0; p < parts; ++p) {
     const f32x2 v = *reinterpret_cast<const f32x2*>(part + ((int64_t)p * m + row) * 2);
-    s1 += v[0];
-    s2 += v[1];
+    const float dm = v[0] - mean;
+    m2 += v[1] + slice_n * dm * dm;
   }
-  const float mean = s1 * inv_n;
-  const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_n), 0.f);
+  const float var = m2 / (slice_n * (float)parts);
   *reinterpret_cast<f32x2*>(stats + 2 * row) = (f32x2){mean, 1.0f / sqrtf(var + eps)};
 }
 
@@ -940,9 +951,9 @@ int hcir_ln_stats_finalize(const float* stats_part, int32_t slices, int64_t m, i
                            float* ln_stats, void* stream) {
   HCIR_ENTER();
   if (!stats_part || !ln_stats || slices <= 0 || m <= 0 || n_features <= 0) return HCIR_ERR_INVALID;
+  if ((int64_t)slices * 64 != n_features) return HCIR_ERR_INVALID;  // slices are 64 features wide
   hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)hcir_cdiv(m, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), stats_part, slices, m, 1.0f / (float)n_features, eps,
-                     ln_stats);
+                     static_cast<hipStream_t>(stream), stats_part, slices, m, 64.0f, eps, ln_stats);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

@@ -178,10 +178,11 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
  * (HP/src/models_vit.py:147-149; torchvision EncoderBlock via HP/src/main_backbone.py:554)
  * without ever writing the normalised tokens:
  *  (1) producer: epilogue HCIR_EPI_BIAS_RESID_F16 with stats_part != NULL also writes, per
- *      stored fp16 row, partial (sum, sum of squares) slices
+ *      stored fp16 row, one (mean, sum of squared deviations from it) pair per 64-feature slice:
  *          stats_part[slice][row][2],  slice < hcir_gemm_stats_slices(n) = n / 64;
- *  (2) hcir_ln_stats_finalize adds the slices in index order (deterministic) and writes
- *          ln_stats[row] = (mean, 1 / sqrt(var + eps)),  var = E[x^2] - mean^2 (biased);
+ *  (2) hcir_ln_stats_finalize combines the slices (Chan's parallel-variance formula, index order:
+ *      deterministic, no E[x^2] - mean^2 cancellation) and writes
+ *          ln_stats[row] = (mean, 1 / sqrt(var + eps)),  var biased (/ n_features = 64 * slices);
  *  (3) consumer: epilogue HCIR_EPI_BIAS_F16 / HCIR_EPI_BIAS_GELU_F16 with ln_stats, ln_c1:
  *      A = the RAW residual rows x (fp16), W' = fp16(gamma o W),
  *          out = act( rstd[m] * (A . W'^T - mean[m] * ln_c1[n]) + bias[n] )

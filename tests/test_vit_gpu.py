@@ -108,6 +108,7 @@ def test_gemm_fused_layernorm(L, m, d, mlp):
     b2 = torch.randn(d, generator=g)
     # residual rows with a per-row offset (mean != 0) and a few large channels
     resid = torch.randn(m, d, generator=g) + torch.randn(m, 1, generator=g) * 2.0
+    resid[: m // 4] += 60.0          # rows with |mean| / std ~ 50: the variance must survive (Chan combination)
     resid[:, 5] *= 20.0
     resid = resid.half()
     new_rows = (resid.float() + a.float() @ w2.float().t() + b2).half()          # what the epilogue stores

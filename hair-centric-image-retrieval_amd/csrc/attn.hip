@@ -35,7 +35,9 @@ struct AttnArgs {
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int TP = 32 * NKT;
-  __shared__ __attribute__((aligned(16))) char lds[2 * TP * 128];
+  // K and V images, then a 4 KB output-transposition tile per wave
+  constexpr bool kTrans = NKT <= 7;  // with 8-9 key tiles the extra 16 KB would cost the second workgroup per CU
+  __shared__ __attribute__((aligned(16))) char lds[2 * TP * 128 + (kTrans ? 4 * 4096 : 0)];
   char* ks = lds;
   char* vs = lds + TP * 128;
 
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
 
-    // ---- store: lane owns query row q0 + r, registers hold head dims ----
-    const int q = q0 + r;
-    if (q < a.nq) {
-      _Float16* orow = a.out + (b * a.nq + q) * ((int64_t)a.h * 64) + head * 64;
+    // ---- store: the lane owns query row q0 + r and 4-dim pieces of it; a direct store would write 16 B of 32
+    //      different rows per instruction (partial lines).  The wave transposes its 32 x 64 tile through 4 KB of
+    //      LDS (16-B chunks XOR-swizzled with row & 7) and stores whole 128-B rows: 8 lanes x 16 B.
+    if constexpr (kTrans) {
+      char* ot = lds + 2 * TP * 128 + wave * 4096 + opaque;
 #pragma unroll
       for (int hdt = 0; hdt < 2; ++hdt) {
 #pragma unroll
@@ -182,7 +185,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           f16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
-          *reinterpret_cast<f16x4*>(orow + 32 * hdt + 8 * g4 + 4 * h) = o;
+          const int chunk = 4 * hdt + g4;  // 16-B chunk = 8 head dims; h picks its 8-B half
+          *reinterpret_cast<f16x4*>(ot + r * 128 + ((chunk ^ (r & 7)) << 4) + 8 * h) = o;
+        }
+      }
+      const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+        const int q = q0 + row;
+        if (q < a.nq)
+          *reinterpret_cast<u32x4*>(a.out + (b * a.nq + q) * ((int64_t)a.h * 64) + head * 64 + cc * 8) = v;
+      }
+    }
+    if constexpr (!kTrans) {
+      const int q = q0 + r;
+      if (q < a.nq) {
+        _Float16* orow = a.out + (b * a.nq + q) * ((int64_t)a.h * 64) + head * 64;
+#pragma unroll
+        for (int hdt = 0; hdt < 2; ++hdt) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
+            *reinterpret_cast<f16x4*>(orow + 32 * hdt + 8 * g4 + 4 * h) = o;
+          }
         }
       }
     }

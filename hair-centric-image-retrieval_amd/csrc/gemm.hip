@@ -799,6 +799,47 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(PatchArgs p, int tiles
   }
   // epilogue: tok[b][1 + p][n] = acc + bias[n] + pos_mult * pos[1 + p][n]
   const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(TokT) == 2) {
+    // fp16 token rows: the wave transposes its 64 x 64 tile through 8 KB of the (now idle) stage buffers and
+    // stores whole 128-B lines; the direct layout below writes 8 B of 32 different rows per instruction
+    // (the same fix took 13 % off the attention kernel)
+    char* ot = lds + wave * 8192;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 32 + r;
+      int64_t m = m0 + wave_m * 64 + row;
+      m = m < mtot ? m : mtot - 1;
+      const float* prow = p.pos + (int64_t)(1 + (int)(m % np)) * p.d;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          int n = n0 + wave_n * 64 + nt * 32 + 8 * grp + 4 * h;
+          n = n < p.d ? n : p.d - 4;  // (d is a multiple of 8: a clamped read, the column is not stored)
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+          const f32x4 ps = *reinterpret_cast<const f32x4*>(prow + n);
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(acc[nt][mt][4 * grp + e] + b[e] + p.pos_mult * ps[e]);
+          *reinterpret_cast<f16x4*>(ot + row * 128 + (((4 * nt + grp) ^ (row & 7)) << 4) + 8 * h) = o;
+        }
+      }
+    }
+    const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + rr;
+      const int64_t m = m0 + wave_m * 64 + row;
+      const int n = n0 + wave_n * 64 + cc * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+      if (m < mtot && n < p.d) {
+        const int64_t bi = m / np;
+        const int pi = (int)(m % np);
+        *reinterpret_cast<u32x4*>(static_cast<_Float16*>(p.tok) + (bi * (np + 1) + 1 + pi) * (int64_t)p.d + n) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int64_t m = m0 + wave_m * 64 + mt * 32 + r;

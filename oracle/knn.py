@@ -30,6 +30,7 @@ _LIB = None
 
 MODE_CHAIN32 = 0
 MODE_F64 = 1
+MODE_CHAIN32_SCALAR = 2  # dot_chain32 one score at a time (the definition the blocked AVX2 path is checked against)
 
 
 def build() -> str:
@@ -128,8 +129,20 @@ def knn_vote(nbr_idx, labels, nclass=None):
 # ---------------------------------------------------------------------------
 def stable_topk_np(scores64: np.ndarray, k: int):
     """Top-k of each row under (score desc, index asc)."""
-    order = np.argsort(-scores64, axis=1, kind="stable")[:, :k]
-    return np.take_along_axis(scores64, order, axis=1), order.astype(np.int64)
+    n = scores64.shape[1]
+    if n <= 4096 or k * 8 >= n:
+        order = np.argsort(-scores64, axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(scores64, order, axis=1), order.astype(np.int64)
+    # wide rows: every element >= the k-th largest value (ties at the boundary included), then the
+    # same stable order on that subset — identical result, no full-row sort
+    vals = np.empty((scores64.shape[0], k), dtype=scores64.dtype)
+    idx = np.empty((scores64.shape[0], k), dtype=np.int64)
+    for i, row in enumerate(scores64):
+        kth = np.partition(row, n - k)[n - k]
+        cand = np.nonzero(row >= kth)[0]                 # ascending indices
+        o = cand[np.argsort(-row[cand], kind="stable")[:k]]
+        vals[i], idx[i] = row[o], o
+    return vals, idx
 
 
 def sklearn_cosine_kneighbors_np(q, g, k):

@@ -37,6 +37,7 @@
 
 #define ORACLE_MODE_CHAIN32 0
 #define ORACLE_MODE_F64 1
+#define ORACLE_MODE_CHAIN32_SCALAR 2 /* the chain as written in dot_chain32, one score at a time */
 
 int hcir_oracle_num_threads(void) {
 #ifdef _OPENMP
@@ -102,8 +103,8 @@ void hcir_oracle_scores(const float* q, int64_t nq, const float* g, int64_t ng, 
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < nq; ++i) {
     for (int64_t j = 0; j < ng; ++j) {
-      float s = mode == ORACLE_MODE_CHAIN32 ? dot_chain32(g + j * d, q + i * d, d)
-                                            : dot_f64(g + j * d, q + i * d, d);
+      float s = mode != ORACLE_MODE_F64 ? dot_chain32(g + j * d, q + i * d, d)
+                                        : dot_f64(g + j * d, q + i * d, d);
       if (gn) s = s * gn[j];
       if (qn) s = s * qn[i];
       out[i * ng + j] = s;
@@ -111,31 +112,127 @@ void hcir_oracle_scores(const float* q, int64_t nq, const float* g, int64_t ng, 
   }
 }
 
+/* ---- blocked AVX2 evaluation of the SAME fp32 chain --------------------------------------------
+ * 64 queries of a block sit transposed ([k][64], zero past d): one gallery element is broadcast
+ * and multiplied into eight 8-lane accumulators, every lane its own fmaf chain over k in the
+ * order of dot_chain32 (fma is commutative in its factors), so each score is bit-identical to
+ * the scalar chain; tests/test_oracle_knn.py compares the two.  Only the evaluation order ACROSS
+ * scores changes, which is what makes 880 x 1M x 768 (config C4 at full size) a seconds-long
+ * check instead of minutes. */
+#include <immintrin.h>
+#define ORACLE_QB 64
+
+static void scores_block_avx2(const float* qT, const float* grow, int d, float* out) {
+  __m256 acc[8];
+  for (int v = 0; v < 8; ++v) acc[v] = _mm256_setzero_ps();
+  const int nchunk = (d + 31) / 32;
+  for (int c = 0; c < nchunk; ++c) {
+    for (int cc = 0; cc < 4; ++cc) {
+      for (int e = 0; e < 4; ++e) {
+        for (int hh = 0; hh < 2; ++hh) {
+          const int k = 32 * c + 8 * cc + e + 4 * hh;
+          const __m256 gv = _mm256_set1_ps(k < d ? grow[k] : 0.f);
+          const float* qk = qT + (size_t)k * ORACLE_QB;
+          for (int v = 0; v < 8; ++v) acc[v] = _mm256_fmadd_ps(gv, _mm256_loadu_ps(qk + 8 * v), acc[v]);
+        }
+      }
+    }
+  }
+  for (int v = 0; v < 8; ++v) _mm256_storeu_ps(out + 8 * v, acc[v]);
+}
+
+static inline void topk_insert(float* v, int64_t* id, int* filled, int k, float s, int64_t j) {
+  if (s != s) return; /* NaN never ranks */
+  if (*filled == k && !better(s, j, v[k - 1], id[k - 1])) return;
+  int p = *filled < k ? *filled : k - 1;
+  while (p > 0 && better(s, j, v[p - 1], id[p - 1])) {
+    v[p] = v[p - 1];
+    id[p] = id[p - 1];
+    --p;
+  }
+  v[p] = s;
+  id[p] = j;
+  if (*filled < k) ++*filled;
+}
+
 /* score = (<g_j, q_i> * gn[j]) * qn[i]; top-k per query, (desc, idx asc). */
 void hcir_oracle_cosine_topk(const float* q, int64_t nq, const float* g, int64_t ng, int32_t d,
                              int32_t k, const float* qn, const float* gn, int64_t idx_base,
                              int mode, float* out_val, int64_t* out_idx) {
+  if (mode == ORACLE_MODE_CHAIN32 && nq * ng >= 4096) {
+    const int dpad = (d + 31) / 32 * 32;
+    const int64_t nblk = (nq + ORACLE_QB - 1) / ORACLE_QB;
+    /* gallery chunks so that (query block, chunk) pairs feed every thread even for one block */
+    int64_t nchunk = 1;
+    const int nthr = hcir_oracle_num_threads();
+    while (nblk * nchunk < 4 * nthr && ng / (nchunk * 2) >= 4096) nchunk *= 2;
+    const int64_t rows_per = (ng + nchunk - 1) / nchunk;
+    float* pv = (float*)malloc((size_t)nblk * nchunk * ORACLE_QB * k * sizeof(float));
+    int64_t* pi = (int64_t*)malloc((size_t)nblk * nchunk * ORACLE_QB * k * sizeof(int64_t));
+    int* pf = (int*)calloc((size_t)nblk * nchunk * ORACLE_QB, sizeof(int));
+#pragma omp parallel
+    {
+      float* qT = (float*)aligned_alloc(32, (size_t)dpad * ORACLE_QB * sizeof(float));
+      float sc[ORACLE_QB];
+#pragma omp for schedule(dynamic, 1) collapse(2)
+      for (int64_t b = 0; b < nblk; ++b) {
+        for (int64_t ch = 0; ch < nchunk; ++ch) {
+          const int64_t i0 = b * ORACLE_QB;
+          const int nb = (int)(nq - i0 < ORACLE_QB ? nq - i0 : ORACLE_QB);
+          memset(qT, 0, (size_t)dpad * ORACLE_QB * sizeof(float));
+          for (int i = 0; i < nb; ++i)
+            for (int kk = 0; kk < d; ++kk) qT[(size_t)kk * ORACLE_QB + i] = q[(i0 + i) * d + kk];
+          const size_t base = ((size_t)b * nchunk + ch) * ORACLE_QB;
+          const int64_t j0 = ch * rows_per, j1 = j0 + rows_per < ng ? j0 + rows_per : ng;
+          for (int64_t j = j0; j < j1; ++j) {
+            scores_block_avx2(qT, g + j * d, d, sc);
+            for (int i = 0; i < nb; ++i) {
+              float s = sc[i];
+              if (gn) s = s * gn[j];
+              if (qn) s = s * qn[i0 + i];
+              topk_insert(pv + (base + i) * k, pi + (base + i) * k, pf + base + i, k, s, j);
+            }
+          }
+        }
+      }
+      free(qT);
+    }
+    /* merge the chunks of a query in chunk order: rows of a later chunk have larger indices,
+     * so topk_insert's (score desc, index asc) order is exactly the single-pass order */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nq; ++i) {
+      const int64_t b = i / ORACLE_QB;
+      const int il = (int)(i % ORACLE_QB);
+      float* v = out_val + i * k;
+      int64_t* id = out_idx + i * k;
+      int filled = 0;
+      for (int64_t ch = 0; ch < nchunk; ++ch) {
+        const size_t slot = ((size_t)b * nchunk + ch) * ORACLE_QB + il;
+        for (int p = 0; p < pf[slot]; ++p) topk_insert(v, id, &filled, k, pv[slot * k + p], pi[slot * k + p]);
+      }
+      for (int p = filled; p < k; ++p) {
+        v[p] = -INFINITY;
+        id[p] = -1;
+      }
+      for (int p = 0; p < filled; ++p) id[p] += idx_base;
+    }
+    free(pv);
+    free(pi);
+    free(pf);
+    return;
+  }
 #pragma omp parallel for schedule(dynamic, 1)
   for (int64_t i = 0; i < nq; ++i) {
     float* v = out_val + i * k;
     int64_t* id = out_idx + i * k;
     int filled = 0;
     for (int64_t j = 0; j < ng; ++j) {
-      float s = mode == ORACLE_MODE_CHAIN32 ? dot_chain32(g + j * d, q + i * d, d)
-                                            : dot_f64(g + j * d, q + i * d, d);
+      float s = (mode == ORACLE_MODE_CHAIN32 || mode == ORACLE_MODE_CHAIN32_SCALAR)
+                    ? dot_chain32(g + j * d, q + i * d, d)
+                    : dot_f64(g + j * d, q + i * d, d);
       if (gn) s = s * gn[j];
       if (qn) s = s * qn[i];
-      if (s != s) continue; /* NaN never ranks */
-      if (filled == k && !better(s, j, v[k - 1], id[k - 1])) continue;
-      int p = filled < k ? filled : k - 1;
-      while (p > 0 && better(s, j, v[p - 1], id[p - 1])) {
-        v[p] = v[p - 1];
-        id[p] = id[p - 1];
-        --p;
-      }
-      v[p] = s;
-      id[p] = j;
-      if (filled < k) ++filled;
+      topk_insert(v, id, &filled, k, s, j);
     }
     for (int p = filled; p < k; ++p) {
       v[p] = -INFINITY;

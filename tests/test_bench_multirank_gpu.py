@@ -44,19 +44,20 @@ print("rank", rank, "ok")
 '''
 
 
-def _run(args, env_extra, timeout=600):
+def _run(args, env_extra, timeout=600, nproc=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                            "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300)] + args,
                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_two_rank_sharded_search_equals_single_scan(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 4])   # 4 ranks + this process stay inside the box's 6-process GPU guard
+def test_multi_rank_sharded_search_equals_single_scan(tmp_path, nproc):
     script = tmp_path / "check.py"
     script.write_text(CHECK.format(root=ROOT))
-    r = _run([str(script)], {})
+    r = _run([str(script)], {}, nproc=nproc)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == nproc
 
 
 def test_bench_two_ranks_rehearsal():

@@ -237,3 +237,153 @@ def test_models_vit_oracle_and_keys():
     assert out.shape == (1, 197, 768)
     big = vit_large_patch16(drop_path_rate=0.0, global_pool=True, init_values=1e-5)
     assert "blocks.23.ls1.gamma" in big.state_dict()
+
+
+# ---------------------------------------------------------------- independent pins built from torch's own transformer
+def _tel_from_tv(sd, pre, d=768, heads=12, mlp=3072):
+    """torch.nn.TransformerEncoderLayer(norm_first=True, gelu, eps 1e-6) IS torch's own pre-LN block:
+    x = x + SA(LN1(x)); x = x + FF(LN2(x)) — the same structure as torchvision's EncoderBlock, composed
+    by torch, not by this build.  Map a torchvision-keyed block into it."""
+    tel = torch.nn.TransformerEncoderLayer(d, heads, mlp, dropout=0.0, activation="gelu", batch_first=True,
+                                           norm_first=True, layer_norm_eps=1e-6).eval()
+    with torch.no_grad():
+        tel.self_attn.in_proj_weight.copy_(sd[pre + "self_attention.in_proj_weight"])
+        tel.self_attn.in_proj_bias.copy_(sd[pre + "self_attention.in_proj_bias"])
+        tel.self_attn.out_proj.weight.copy_(sd[pre + "self_attention.out_proj.weight"])
+        tel.self_attn.out_proj.bias.copy_(sd[pre + "self_attention.out_proj.bias"])
+        tel.norm1.weight.copy_(sd[pre + "ln_1.weight"]); tel.norm1.bias.copy_(sd[pre + "ln_1.bias"])
+        tel.norm2.weight.copy_(sd[pre + "ln_2.weight"]); tel.norm2.bias.copy_(sd[pre + "ln_2.bias"])
+        tel.linear1.weight.copy_(sd[pre + "mlp.0.weight"]); tel.linear1.bias.copy_(sd[pre + "mlp.0.bias"])
+        tel.linear2.weight.copy_(sd[pre + "mlp.3.weight"]); tel.linear2.bias.copy_(sd[pre + "mlp.3.bias"])
+    return tel
+
+
+def _randomise(sd, seed):
+    """Non-trivial values for every parameter (zero biases / unit LayerNorm gains at init would hide a
+    swapped or dropped term)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point:
+            out[k] = v.clone()
+        elif k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or k.endswith("ln.weight") or "norm" in k and k.endswith("weight"):
+            out[k] = 1.0 + 0.2 * torch.randn(v.shape, generator=g)
+        elif v.dim() >= 2 and v.shape[-1] > 8:
+            out[k] = v.clone() if v.abs().sum() > 0 else 0.02 * torch.randn(v.shape, generator=g)
+        else:
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+    return out
+
+
+def test_vit_oracle_block_equals_torch_transformer_encoder_layer():
+    """an INDEPENDENT composition of the same block.  torch's TransformerEncoderLayer /
+    TransformerEncoder (slow path forced by grad mode being irrelevant: eval + no nested tensors) against
+    oracle.vit._tv_encoder_block and the 12-block stack of vitwrapper_forward."""
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(3)
+    m = SHAM2("vit_b_16").eval()
+    sd = _randomise(m.state_dict(), 5)
+    h = torch.randn(2, 197, 768)
+    # torch's fused "fast path" is a different kernel; pin against the documented python path too
+    for fast in (False, True):
+        torch.backends.mha.set_fastpath_enabled(fast)
+        try:
+            with torch.no_grad():
+                pre = "backbone.encoder.layers.encoder_layer_4."
+                ref = _tel_from_tv(sd, pre)(h)
+                got = ovit._tv_encoder_block(sd, pre, h, 12)
+                assert (ref - got).abs().max() <= 2e-5 * ref.abs().max(), fast
+                # the whole stack + final LayerNorm: nn.TransformerEncoder(layers, norm)
+                layers = [_tel_from_tv(sd, f"backbone.encoder.layers.encoder_layer_{i}.") for i in range(12)]
+                enc = torch.nn.TransformerEncoder(layers[0], 12, norm=torch.nn.LayerNorm(768, eps=1e-6),
+                                                  enable_nested_tensor=False).eval()
+                for i in range(12):
+                    enc.layers[i].load_state_dict(layers[i].state_dict())
+                enc.norm.weight.copy_(sd["backbone.encoder.ln.weight"])
+                enc.norm.bias.copy_(sd["backbone.encoder.ln.bias"])
+                x = torch.randn(2, 3, 224, 224)
+                # tokens as ViTWrapper builds them (HP/src/main_backbone.py:543-554), pos added twice
+                t = F.conv2d(x, sd["backbone.conv_proj.weight"], sd["backbone.conv_proj.bias"], stride=16)
+                t = t.flatten(2).transpose(1, 2)
+                t = torch.cat((sd["backbone.cls_token"].expand(2, -1, -1), t), 1)
+                t = t + sd["backbone.pos_embedding"] + sd["backbone.encoder.pos_embedding"]
+                ref_tok = enc(t)
+                cls, pooled = ovit.vitwrapper_forward(sd, x, "backbone.")
+                assert (ref_tok[:, 0] - cls).abs().max() <= 5e-5 * ref_tok.abs().max(), fast
+                assert (ref_tok[:, 1:].mean(1) - pooled).abs().max() <= 5e-5 * ref_tok.abs().max(), fast
+        finally:
+            torch.backends.mha.set_fastpath_enabled(True)
+
+
+def test_models_vit_oracle_equals_torch_transformer_encoder():
+    """models_vit.forward_features (timm layout: packed qkv Linear, q pre-scaled, max-subtracted softmax,
+    no final norm) against torch's TransformerEncoder with the qkv Linear mapped onto in_proj."""
+    from hcir.models_vit import vit_base_patch16
+    torch.manual_seed(4)
+    m = vit_base_patch16(drop_path_rate=0.0, global_pool=True, init_values=None).eval()
+    sd = _randomise(m.state_dict(), 6)
+    sd["pos_embed"] = 0.02 * torch.randn(sd["pos_embed"].shape, generator=torch.Generator().manual_seed(7))
+    layers = []
+    for i in range(12):
+        q = f"blocks.{i}."
+        tel = torch.nn.TransformerEncoderLayer(768, 12, 3072, dropout=0.0, activation="gelu", batch_first=True,
+                                               norm_first=True, layer_norm_eps=1e-6).eval()
+        with torch.no_grad():
+            tel.self_attn.in_proj_weight.copy_(sd[q + "attn.qkv.weight"])
+            tel.self_attn.in_proj_bias.copy_(sd[q + "attn.qkv.bias"])
+            tel.self_attn.out_proj.weight.copy_(sd[q + "attn.proj.weight"])
+            tel.self_attn.out_proj.bias.copy_(sd[q + "attn.proj.bias"])
+            tel.norm1.weight.copy_(sd[q + "norm1.weight"]); tel.norm1.bias.copy_(sd[q + "norm1.bias"])
+            tel.norm2.weight.copy_(sd[q + "norm2.weight"]); tel.norm2.bias.copy_(sd[q + "norm2.bias"])
+            tel.linear1.weight.copy_(sd[q + "mlp.fc1.weight"]); tel.linear1.bias.copy_(sd[q + "mlp.fc1.bias"])
+            tel.linear2.weight.copy_(sd[q + "mlp.fc2.weight"]); tel.linear2.bias.copy_(sd[q + "mlp.fc2.bias"])
+        layers.append(tel)
+    x = torch.randn(2, 3, 224, 224)
+    with torch.no_grad():
+        t = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=16).flatten(2).transpose(1, 2)
+        t = torch.cat((sd["cls_token"].expand(2, -1, -1), t), 1) + sd["pos_embed"]
+        for tel in layers:
+            t = tel(t)
+        got = ovit.models_vit_forward_features(sd, x)
+    assert (t - got).abs().max() <= 5e-5 * t.abs().max()
+
+
+def test_projection_head_oracle_equals_torch_sequential():
+    """lightly's SimCLRProjectionHead is Sequential(Linear(no bias), BN1d, ReLU, Linear(no bias), BN1d)
+    (SURVEY.md Appendix A): compose exactly that from torch.nn and compare."""
+    g = torch.Generator().manual_seed(8)
+    seq = torch.nn.Sequential(torch.nn.Linear(768, 768, bias=False), torch.nn.BatchNorm1d(768), torch.nn.ReLU(),
+                              torch.nn.Linear(768, 512, bias=False), torch.nn.BatchNorm1d(512)).eval()
+    with torch.no_grad():
+        for mod in seq:
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.2, generator=g); mod.running_var.uniform_(0.5, 1.5, generator=g)
+                mod.weight.normal_(1, 0.1, generator=g); mod.bias.normal_(0, 0.1, generator=g)
+    sd = {"projection_head.layers." + k: v for k, v in seq.state_dict().items()}
+    x = torch.randn(16, 768, generator=g)
+    with torch.no_grad():
+        ref = seq(x)
+    got = ovit.projection_head_forward(sd, x)
+    assert (ref - got).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_blocked_oracle_scan_equals_scalar_chain():
+    """The AVX2-blocked evaluation (used so that 880 x 1M x 768 is a seconds-long check) must equal the
+    scalar chain bit for bit, values and indices, including planted ties and ragged d."""
+    rng = np.random.default_rng(0)
+    for nq, ng, d, k in ((70, 5000, 72, 7), (3, 40000, 768, 10), (130, 9000, 100, 50), (65, 4099, 33, 16)):
+        q = rng.standard_normal((nq, d), dtype=np.float32)
+        g = rng.standard_normal((ng, d), dtype=np.float32)
+        g[ng // 2] = g[3]
+        g[ng - 1] = g[3]
+        q[0] = g[3]
+        qn, gn = oknn.row_invnorm(q, 1e-12), oknn.row_invnorm(g, 1e-12)
+        v1, i1 = oknn.cosine_topk(q, g, k, qn=qn, gn=gn, idx_base=5)
+        v2, i2 = oknn.cosine_topk(q, g, k, qn=qn, gn=gn, idx_base=5, mode=oknn.MODE_CHAIN32_SCALAR)
+        np.testing.assert_array_equal(i1, i2)
+        np.testing.assert_array_equal(v1, v2)
+        v1, i1 = oknn.cosine_topk(q, g, k)
+        v2, i2 = oknn.cosine_topk(q, g, k, mode=oknn.MODE_CHAIN32_SCALAR)
+        np.testing.assert_array_equal(i1, i2)
+        np.testing.assert_array_equal(v1, v2)
+        assert list(i1[0, :3]) == [3, ng // 2, ng - 1]

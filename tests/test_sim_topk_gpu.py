@@ -184,3 +184,53 @@ def test_topk_merge(ops):
     rv, ri = oknn.topk_merge(vals, idx, kout)
     np.testing.assert_array_equal(oi.cpu().numpy(), ri)
     np.testing.assert_array_equal(ov.cpu().numpy(), rv)
+
+
+# ---- config C5 geometry (BASELINE.json configs[4]): d = 1024, top-50, fp16 / bf16 storage -------------------
+def _scores64_rounded(qd, gd, chunk=65536):
+    """float64 scores of the ROUNDED inputs (exact products, exact sums up to fp64), gallery in chunks."""
+    qr = qd.float().cpu().numpy().astype(np.float64)
+    out = np.empty((qr.shape[0], gd.shape[0]), dtype=np.float64)
+    for s0 in range(0, gd.shape[0], chunk):
+        out[:, s0:s0 + chunk] = qr @ gd[s0:s0 + chunk].float().cpu().numpy().astype(np.float64).T
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nq,ng", [(32, 40000), (64, 40000), (200, 40000), (32, 300000), (64, 300000),
+                                   (200, 300000)])
+def test_sim_topk_c5_top50_d1024(ops, dtype, nq, ng):
+    """The 64-entry-list kernel (16 < k <= 64) with its 4-slot DMA ring, with and without the prefix pass
+    (N >= 32768 takes it; the 300 000-row gallery runs a 16 K-row prefix), fp16 AND bf16, at config C5's row
+    length and k.  Checked against float64 scores of the same rounded inputs: values within
+    1e-5, indices exact wherever the oracle's neighbouring gaps exceed that."""
+    d, k = 1024, 50
+    q, g = _rand((nq, d), 41), _rand((ng, d), 42)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g[ng - 5] = g[11]                        # an exact duplicate far behind the prefix
+    q[0] = g[11]
+    qd, gd = torch.from_numpy(q).cuda().to(dtype), torch.from_numpy(g).cuda().to(dtype)
+    val, idx = ops.sim_topk(qd, gd, k, idx_base=3)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy() - 3
+    rv, ri = oknn.stable_topk_np(_scores64_rounded(qd, gd), k + 1)
+    np.testing.assert_allclose(val, rv[:, :k], atol=1e-5, rtol=0)
+    gap = rv[:, :-1] - rv[:, 1:]
+    safe = np.minimum(np.concatenate([np.full((nq, 1), np.inf), gap[:, :-1]], 1), gap) > 1e-5
+    np.testing.assert_array_equal(idx[safe], ri[:, :k][safe])
+    assert safe.mean() > 0.9                 # the comparison is not vacuous
+    assert list(idx[0, :2]) == [11, ng - 5]  # identical rows give identical fp32 chains: tie -> smaller index
+    assert (np.diff(val, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("nq,ng,d,k", [(32, 40000, 1024, 50), (64, 50000, 768, 50), (130, 70000, 256, 33),
+                                       (16, 300000, 128, 64)])
+def test_sim_topk_f32_top50_bit_exact(ops, nq, ng, d, k):
+    """fp32 storage through the same 64-entry-list + prefix path: bit-exact against the C oracle."""
+    q, g = _rand((nq, d), 43), _rand((ng, d), 44)
+    g[ng - 1] = g[2]
+    q[1] = g[2]
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), k)
+    rv, ri = oknn.cosine_topk(q, g, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)

@@ -888,11 +888,13 @@ template <int EPI>
 void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
   const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
   const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
-  static const bool mf16 = [] { const char* e = getenv("HCIR_GEMM_MFMA"); return !(e && e[0] == '3'); }();
-  if (mf16)
-    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
-  else
-    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+  // MFMA shape: a BUILD flag (make CXXFLAGS+=-DHCIR_GEMM_MFMA32 builds the 32x32x16 variant for A/B runs through
+  // HCIR_LIB_PATH); the library reads no environment variables
+#ifdef HCIR_GEMM_MFMA32
+  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+#else
+  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+#endif
 }
 
 // (mean, M2) of the 64-feature slices of hcir_gemm_f16_fused -> (mean, rstd) per row by Chan's parallel-variance

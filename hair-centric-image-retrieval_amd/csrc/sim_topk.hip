@@ -984,10 +984,14 @@ void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
   }
 }
 
-// HCIR_SCAN_BIG=0 keeps the list-keeping scan for every query count (A/B runs)
+// -DHCIR_SCAN_NO_BIG (build flag) keeps the list-keeping scan for every query count (A/B libraries through
+// HCIR_LIB_PATH); the library reads no environment variables
 inline bool big_scan_enabled() {
-  static const bool on = [] { const char* e = getenv("HCIR_SCAN_BIG"); return !(e && e[0] == '0'); }();
-  return on;
+#ifdef HCIR_SCAN_NO_BIG
+  return false;
+#else
+  return true;
+#endif
 }
 
 void launch_scan_dtype(int dtype, const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {

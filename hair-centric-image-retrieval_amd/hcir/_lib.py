@@ -63,6 +63,10 @@ SIGNATURES = {
     "hcir_positive_masking": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp,
                                       c_vp]),
     "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "hcir_knn_vote": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "hcir_confusion_matrix": (c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "hcir_retrieval_metrics": (c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp]),
 }
 
 

@@ -7,7 +7,9 @@ Differences from the reference, all behind the same interface:
     sklearn fit + full distance matrix per k (:79-82 recomputes it 7 times); every k of the
     sweep is a prefix of that list;
   * the uniform-weight vote (mode of the k neighbour labels, smallest label on ties — sklearn
-    KNeighborsClassifier.predict) is a host-side numpy bincount.
+    KNeighborsClassifier.predict) of ALL k of the sweep is one hcir_knn_vote launch over that list, and
+    accuracy / confusion-matrix counts come from hcir_confusion_matrix: labels and predictions stay in HBM;
+    only the per-k report (text) is assembled on the host.
 linear_probe_eval / save_umap / compute_intra_inter_variance are sklearn/umap analytics outside
 the hot path and raise NotImplementedError.
 """
@@ -101,19 +103,24 @@ class Classifier:
             f.write("KNN Evaluation Results\n")
             f.write("=" * 50 + "\n\n")
         n_train = self.training_features.shape[0]
-        kmax = max(k for k in ks if k <= n_train) if any(k <= n_train for k in ks) else 0
-        nbr = None
-        if kmax:
-            _, idx = self.kneighbors(kmax)
-            nbr = self.training_labels.numpy()[idx.cpu().numpy()]
+        valid = sorted({k for k in ks if k <= n_train})
         y_true = self.testing_labels.numpy()
         nclass = int(max(self.training_labels.max(), self.testing_labels.max())) + 1
+        preds = {}
+        if valid:
+            from . import metrics
+            _, idx = self.kneighbors(valid[-1])
+            dev = idx.device
+            pred = metrics.knn_vote(idx, self.training_labels.to(dev), valid, nclass)   # [len(valid), n_test]
+            yt = self.testing_labels.to(dev)
+            for j, k in enumerate(valid):
+                cm = metrics.confusion_matrix(yt, pred[j].contiguous(), nclass)
+                preds[k] = (pred[j].cpu().numpy(), float(cm.diagonal().sum().item()) / max(len(y_true), 1))
         for k in ks:
             if k > n_train:  # sklearn raises here and the reference's sweep stops
                 raise ValueError(f"Expected n_neighbors <= n_samples_fit, but n_neighbors = {k}, "
                                  f"n_samples_fit = {n_train}, n_samples = {len(y_true)}")
-            y_pred = knn_vote(nbr[:, :k], nclass)
-            acc = float((y_pred == y_true).mean())
+            y_pred, acc = preds[k]
             report, cm = _report(y_true, y_pred)
             with open(file_path, "a") as f:
                 f.write(f"Results for k={k}\n")

@@ -7,7 +7,8 @@ call pattern to translate.  The sharded search is new capability defined by nort
   1. all-gather of the query embeddings   [Q/P, D] per rank   (RCCL over xGMI)
   2. local hcir_sim_topk of ALL Q queries against the local shard -> (val, idx)[Q, k]
      with GLOBAL row indices
-  3. all-gather of the per-shard top-k    Q*k*12 B per rank
+  3. all-gather of the per-shard top-k    Q*k*12 B per rank, ONE collective: (fp32 value, int64 index) travel
+     as one int32 record [Q, 3k] (value bits | index words) into one preallocated [P, Q, 3k] buffer
   4. hcir_topk_merge of the P lists with the global tie-break (score desc, index asc)
      -> identical to a single-GPU scan of the whole gallery.
 
@@ -30,17 +31,35 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _all_gather(tensor: torch.Tensor, world: int, group=None):
-    """all_gather of equal-shape tensors.  RCCL ("nccl") gathers device tensors in place; under the
-    gloo REHEARSAL backend (several ranks sharing one GPU, CPU tests) the payload hops through the host."""
+def _all_gather_into(tensor: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """ONE all-gather of equal-shape tensors into a [world, *shape] buffer (no list of outputs, no stack / cat
+    afterwards).  RCCL ("nccl") gathers device tensors in place; under the gloo REHEARSAL backend (several
+    ranks sharing one GPU, CPU tests) the payload hops through the host."""
+    tensor = tensor.contiguous()
     if dist.get_backend(group) == "gloo" and tensor.is_cuda:
         host = tensor.cpu()
-        out = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(out, host, group=group)
-        return [o.to(tensor.device) for o in out]
-    out = [torch.empty_like(tensor) for _ in range(world)]
-    dist.all_gather(out, tensor.contiguous(), group=group)
-    return out
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)   # (concatenated along dim 0: the form every backend takes)
+        return out.to(tensor.device).view((world,) + tuple(tensor.shape))
+    out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor, group=group)
+    return out.view((world,) + tuple(tensor.shape))
+
+
+def pack_topk(val: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """(fp32 [Q,k], int64 [Q,k]) -> int32 [Q, 3k]: the value bits, then the index as two 32-bit words."""
+    q, k = val.shape
+    rec = torch.empty((q, 3 * k), dtype=torch.int32, device=val.device)
+    rec[:, :k] = val.contiguous().view(torch.int32)
+    rec[:, k:] = idx.contiguous().view(torch.int32)
+    return rec
+
+
+def unpack_topk(rec: torch.Tensor, k: int):
+    """int32 [..., 3k] -> (fp32 [..., k], int64 [..., k])."""
+    val = rec[..., :k].contiguous().view(torch.float32)
+    idx = rec[..., k:].contiguous().view(torch.int64)
+    return val, idx
 
 
 class ShardedGallery:
@@ -64,7 +83,8 @@ class ShardedGallery:
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return q_local
-        return torch.cat(_all_gather(q_local, self.world, self.group), 0)
+        out = _all_gather_into(q_local, self.world, self.group)      # [P, Q/P, D], rank-major == row order
+        return out.view(-1, q_local.shape[1])
 
     def search_begin(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
         """Enqueue the local scan of this rank's shard; returns a handle for search_finish."""
@@ -86,9 +106,9 @@ class ShardedGallery:
             val, idx = torch.cat([val, pad_v], 1), torch.cat([idx, pad_i], 1)
         if self.world == 1:
             return val, idx
-        vals = _all_gather(val, self.world, self.group)
-        idxs = _all_gather(idx, self.world, self.group)
-        return self.ops.topk_merge(torch.stack(vals, 0), torch.stack(idxs, 0), k)
+        rec = _all_gather_into(pack_topk(val, idx), self.world, self.group)   # [P, Q, 3k]
+        vals, idxs = unpack_topk(rec, k)
+        return self.ops.topk_merge(vals, idxs, k)
 
     def search(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
         """Top-k of every query in q_all over the WHOLE (sharded) gallery; same result on all ranks."""

@@ -2,8 +2,16 @@
 
   HairEncoder(ckpt_path, model_name="vit_base_patch16", device=None)   :22-41
   .extract_features(images) -> CLS of forward_features (no final norm)   :89-101,208-212
+  .extract_dataset_features(data_path, batch_size, num_workers, save_dir)   :103-142
+  .encode_single_image(image_path)                                       :165-178
   .retrieve_similar_images(query_embedding, all_embeddings, all_paths, top_k=5)  :180-198
   .load_embeddings / .check_embeddings_exist  (embeddings.npy + image_paths.txt)  :144-163
+
+Image pipeline (:43-50): Resize(224, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize.  Resize and crop
+run on the host with PIL (the decode is host PIL anyway); the crop window travels as RGB8 and ToTensor +
+Normalize run on the device (hcir_knn_transform_u8, bit-identical to the torchvision arithmetic).
+`ImageFolder` restates torchvision.datasets.ImageFolder's directory contract (class sub-folders in sorted
+order, files in sorted order, its extension list); torchvision is not a dependency.
 
 cosine_similarity([q], G) + argsort[::-1][:top_k] becomes one hcir_sim_topk call with both
 inverse norms folded in (embeddings on this path are NOT pre-normalised, :196 NOTE in
@@ -19,6 +27,51 @@ import numpy as np
 import torch
 
 from . import models_vit, ops
+from .transform import center_window_u8, knn_transform, knn_transform_u8
+
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+
+class ImageFolder:
+    """torchvision.datasets.ImageFolder's contract: root/<class>/<...>/<image>; classes = sorted sub-folder
+    names; samples = [(path, class_index)] walking each class folder in sorted order."""
+
+    def __init__(self, root: str, transform=None):
+        self.root = root
+        self.transform = transform
+        self.classes = sorted(e.name for e in os.scandir(root) if e.is_dir())
+        if not self.classes:
+            raise FileNotFoundError(f"Couldn't find any class folder in {root}.")
+        self.class_to_idx = {c: i for i, c in enumerate(self.classes)}
+        self.samples = []
+        for c in self.classes:
+            for d, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXTENSIONS):
+                        self.samples.append((os.path.join(d, f), self.class_to_idx[c]))
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        path, target = self.samples[i]
+        with Image.open(path) as im:
+            im = im.convert("RGB")
+        return (self.transform(im) if self.transform else im), target
+
+
+def resize_shorter_side(image, size: int = 224):
+    """torchvision transforms.Resize(size, interpolation=3) on a PIL image: the shorter side becomes `size`,
+    the other int(size * long / short), PIL bicubic (src/models/hair_encoder.py:46)."""
+    from PIL import Image
+    w, h = image.size
+    short, long = (w, h) if w <= h else (h, w)
+    if short == size:
+        return image
+    new_short, new_long = size, int(size * long / short)
+    nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+    return image.resize((nw, nh), Image.BICUBIC)
 
 
 class FeatureExtractor:
@@ -46,6 +99,7 @@ class HairEncoder:
         self.feature_extractor = FeatureExtractor(self.model)
         self._gallery_key = None
         self._gallery = None
+        self._gallery_ref = None
 
     def _build_model(self):
         return models_vit.__dict__[self.model_name](drop_path_rate=0.1, global_pool=True, init_values=None)
@@ -72,14 +126,74 @@ class HairEncoder:
         return (os.path.exists(os.path.join(save_dir, "embeddings.npy"))
                 and os.path.exists(os.path.join(save_dir, "image_paths.txt")))
 
+    # ---- image pipeline (:43-50) ----
+    def _get_transform(self):
+        """Host form with the reference's signature: PIL -> fp32 [3,224,224]."""
+        return lambda im: knn_transform(resize_shorter_side(im, 224), 224)
+
+    @property
+    def transform(self):
+        return self._get_transform()
+
+    @staticmethod
+    def _window_u8(im) -> torch.Tensor:
+        return center_window_u8(resize_shorter_side(im, 224), 224)
+
+    def extract_dataset_features(self, data_path, batch_size=64, num_workers=8, save_dir="embeddings"):
+        """Embed every image of an ImageFolder tree, save embeddings.npy + image_paths.txt (:103-142).
+        Decode / resize / crop in DataLoader workers (RGB8 windows), ToTensor + Normalize + ViT on the device;
+        embeddings stay in HBM until the single copy back at the end."""
+        from torch.utils.data import DataLoader
+        print(f"Loading dataset from: {data_path}")
+        dataset = ImageFolder(data_path, transform=self._window_u8)
+        loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+        feats, all_paths = [], []
+        with torch.no_grad():
+            for wins, _ in loader:
+                x = knn_transform_u8(wins.to(self.device, non_blocking=True))
+                feats.append(self.extract_features(x).float().clone())   # the engine re-uses its buffers
+                start_idx = len(all_paths)
+                all_paths.extend([dataset.samples[i][0] for i in range(start_idx, start_idx + wins.size(0))])
+        all_embeddings = torch.cat(feats, 0).cpu().numpy()
+        self.save_embeddings(all_embeddings, all_paths, save_dir)
+        print(f"Saved {all_embeddings.shape[0]} embeddings and paths to {save_dir}")
+        return all_embeddings, all_paths
+
+    def encode_single_image(self, image_path):
+        """One image -> embedding (np.ndarray [D]) (:165-178)."""
+        from PIL import Image
+        with Image.open(image_path) as im:
+            win = self._window_u8(im.convert("RGB"))
+        x = knn_transform_u8(win.to(self.device))
+        return self.extract_features(x).float().cpu().numpy()[0]
+
     # ---- retrieval ----
+    def set_gallery(self, all_embeddings) -> None:
+        """Upload a gallery (and its inverse norms) into HBM.  retrieve_similar_images does this itself;
+        call it again after editing the array IN PLACE (the cache cannot see that)."""
+        g = torch.as_tensor(np.ascontiguousarray(all_embeddings, dtype=np.float32)).to(self.device)
+        self._gallery = (g, ops.row_invnorm(g, 1e-12))
+        self._gallery_ref = all_embeddings            # strong reference: the id cannot be recycled
+        self._gallery_key = self._fingerprint(all_embeddings)
+
+    @staticmethod
+    def _fingerprint(a):
+        """Cheap content check of the cached array: buffer address, shape and a checksum of a few rows."""
+        a = np.asarray(a)
+        n = a.shape[0]
+        rows = sorted({0, n // 3, (2 * n) // 3, n - 1}) if n else []
+        ptr = a.__array_interface__["data"][0]
+        return (ptr, a.shape, str(a.dtype), tuple(float(np.asarray(a[r], dtype=np.float64).sum()) for r in rows))
+
+    def invalidate_gallery(self) -> None:
+        self._gallery = self._gallery_ref = self._gallery_key = None
+
     def _resident(self, all_embeddings):
-        """Upload the gallery once and keep it (and its inverse norms) resident in HBM."""
-        key = (id(all_embeddings), getattr(all_embeddings, "shape", None))
-        if key != self._gallery_key:
-            g = torch.as_tensor(np.ascontiguousarray(all_embeddings, dtype=np.float32)).to(self.device)
-            self._gallery = (g, ops.row_invnorm(g, 1e-12))
-            self._gallery_key = key
+        """The gallery resident in HBM; re-uploaded when another array (or changed content) is passed.
+        The reference recomputes against the passed array on every call (:193)."""
+        if getattr(self, "_gallery_ref", None) is not all_embeddings \
+                or self._gallery_key != self._fingerprint(all_embeddings):
+            self.set_gallery(all_embeddings)
         return self._gallery
 
     def retrieve_similar_images(self, query_embedding, all_embeddings, all_paths, top_k=5):

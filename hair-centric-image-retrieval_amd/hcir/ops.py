@@ -66,21 +66,24 @@ def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 class _WorkspaceCache:
-    """Grow-only per-device scratch buffer (the C ABI allocates nothing itself)."""
+    """Scratch buffers for the C ABI (which allocates nothing itself), one per (device, stream): two streams
+    never share a buffer, so concurrent calls cannot race on it.  A buffer grows on demand and is dropped when a
+    much smaller one is asked for (a one-off k = 642 sweep does not pin its gigabytes for the process lifetime)."""
 
     def __init__(self):
         self._buf = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self._buf.get(key)
-        if b is None or b.numel() < nbytes:
+        if b is None or b.numel() < nbytes or b.numel() > max(8 * nbytes, 64 << 20):
             b = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
             self._buf[key] = b
         return b
 
 
 _ws = _WorkspaceCache()
+WORKSPACE_LIMIT_BYTES = 1 << 30   # sim_topk splits its queries into chunks whose workspace stays below this
 
 
 def sim_topk(q: torch.Tensor, g: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None,
@@ -110,13 +113,23 @@ def sim_topk(q: torch.Tensor, g: torch.Tensor, k: int, q_inv_norm: Optional[torc
             if t.dtype != torch.float32:
                 raise HcirError(f"{n} must be fp32")
     L = _lib.lib()
-    wsb = L.hcir_sim_topk_workspace_bytes(nq, ng, d, k, _DT[q.dtype])
-    ws = _ws.get(q.device, wsb)
     val = torch.empty((nq, k), dtype=torch.float32, device=q.device)
     idx = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-    check(L.hcir_sim_topk(q.data_ptr(), nq, g.data_ptr(), ng, d, k, _DT[q.dtype], _ptr(q_inv_norm),
-                          _ptr(g_inv_norm), idx_base, val.data_ptr(), idx.data_ptr(), ws.data_ptr(),
-                          ws.numel(), _stream(q)), "hcir_sim_topk")
+    # bounded workspace: the partial lists are 2 * 512 * nq * {16,32,64} * 4 B (270 KB per query at k > 32), so a
+    # large query set is scanned in chunks (queries are independent; each chunk re-streams the gallery)
+    chunk = nq
+    while chunk > 128 and L.hcir_sim_topk_workspace_bytes(chunk, ng, d, k, _DT[q.dtype]) > WORKSPACE_LIMIT_BYTES:
+        chunk = (chunk + 1) // 2
+    if chunk < nq:
+        chunk = (chunk + 127) // 128 * 128
+    for s0 in range(0, nq, chunk):
+        n = min(chunk, nq - s0)
+        wsb = L.hcir_sim_topk_workspace_bytes(n, ng, d, k, _DT[q.dtype])
+        ws = _ws.get(q.device, wsb)
+        qn = None if q_inv_norm is None else q_inv_norm[s0:s0 + n]
+        check(L.hcir_sim_topk(q[s0:s0 + n].data_ptr(), n, g.data_ptr(), ng, d, k, _DT[q.dtype], _ptr(qn),
+                              _ptr(g_inv_norm), idx_base, val[s0:s0 + n].data_ptr(), idx[s0:s0 + n].data_ptr(),
+                              ws.data_ptr(), ws.numel(), _stream(q)), "hcir_sim_topk")
     return val, idx
 
 

@@ -307,24 +307,22 @@ class VitEngine:
 
 
 class EngineCache:
-    """Builds the VitEngine lazily and rebuilds it when parameters or device change
-    (load_state_dict / .to() bump tensor._version or replace .data)."""
+    """Builds the VitEngine lazily and rebuilds it when parameters or device change.
+
+    Every call fingerprints EVERY parameter (data_ptr, _version): load_state_dict, optimizer steps, .to() and
+    in-place ops all bump one of the two (~50 us of host time per forward for ~150 tensors).  What it cannot see
+    is a write through `p.data` / a raw pointer, which bumps neither: call `invalidate()` after such an edit."""
 
     def __init__(self):
         self._engine: Optional[VitEngine] = None
         self._key = None
 
+    def invalidate(self) -> None:
+        self._engine, self._key = None, None
+
     def get(self, params, make_spec, device: torch.device) -> VitEngine:
-        # cheap per-call check (first / last parameter), full fingerprint every 64th call: the
-        # fingerprint walks ~150 tensors (~0.1 ms of host time per forward otherwise)
-        self._calls = getattr(self, "_calls", 0) + 1
-        quick = (str(device), DEFAULT_RESID_DTYPE, params[0].data_ptr(), params[0]._version,
-                 params[-1].data_ptr(), params[-1]._version)
-        if self._engine is not None and quick == getattr(self, "_quick", None) and self._calls % 64:
-            return self._engine
         key = (str(device), DEFAULT_RESID_DTYPE) + tuple((p.data_ptr(), p._version) for p in params)
         if self._engine is None or key != self._key:
             self._engine = VitEngine(make_spec(), device)
             self._key = key
-        self._quick = quick
         return self._engine

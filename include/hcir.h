@@ -268,6 +268,37 @@ int hcir_positive_masking(const float* images, int64_t b, int32_t c, int32_t h, 
                           float threshold, const float* u, const float* keys, float* out,
                           int32_t* n_masked, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * What the reference does with the top-k list, on the device.
+ * `ks` is a HOST array of nk <= 16 strictly ascending values, each in [1, kmax].
+ * ------------------------------------------------------------------ */
+
+/* KNeighborsClassifier(n_neighbors=k, metric="cosine").predict for EVERY k of the sweep from ONE
+ * top-kmax neighbour list (HP/src/classification_engine.py:71,79-82 re-fits and re-scans per k):
+ * uniform-weight mode of the first k neighbour labels, smallest label on ties (scipy.stats.mode as sklearn
+ * uses it).  nbr_idx [nq][kmax] as written by hcir_sim_topk (idx_base is subtracted), labels [nlabels] in
+ * [0, nclass), nclass <= 16384; pred [nk][nq].  *bad (device int, zeroed by the caller) is set when a
+ * neighbour slot is empty or a label is out of range. */
+int hcir_knn_vote(const int64_t* nbr_idx, int64_t nq, int32_t kmax, int64_t idx_base, const int64_t* labels,
+                  int64_t nlabels, int32_t nclass, const int32_t* ks, int32_t nk, int64_t* pred, int32_t* bad,
+                  void* stream);
+
+/* sklearn confusion_matrix counts (HP/src/classification_engine.py:85): cm[t][p] += 1 over n samples;
+ * cm [nclass][nclass] int32 zeroed by the caller; accuracy_score (:83) is its trace / n. */
+int hcir_confusion_matrix(const int64_t* y_true, const int64_t* y_pred, int64_t n, int32_t nclass, int32_t* cm,
+                          int32_t* bad, void* stream);
+
+/* Recall@K and AP@K of a retrieved list against per-query ground-truth ids
+ * (experiments/DualViewHair/scripts/quantitative_eval.py:194-209):
+ *   hit[s][q] = any ground-truth id among the first ks[s] retrieved ids
+ *   ap[s][q]  = ( sum over hit ranks i < ks[s] of hits_so_far / (i + 1) ) / min(|gt_q|, ks[s]),  0 if |gt_q| = 0
+ * (fp64, summed in rank order like the reference's Python floats).  retrieved [nq][kmax] (ids < 0 = empty),
+ * gt [nq][gmax] padded with -1.  recall_mean / map_mean [nk] (optional, both or neither): the means over the
+ * queries in index order (:228-234). */
+int hcir_retrieval_metrics(const int64_t* retrieved, int64_t nq, int32_t kmax, const int64_t* gt, int32_t gmax,
+                           const int32_t* ks, int32_t nk, int32_t* hit, double* ap, double* recall_mean,
+                           double* map_mean, void* stream);
+
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 

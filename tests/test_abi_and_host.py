@@ -133,3 +133,48 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] is not None
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_hair_retrieval_cli_flags_and_image_folder(tmp_path, golden_dir):
+    """Flags and defaults of src/hair_retrieval.py:8-57 (paths excepted: the reference's defaults are the authors'
+    private NAS locations), torchvision ImageFolder's directory contract, Resize(224)'s output size rule."""
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location(
+        "hair_cli", os.path.join(ROOT, "hair-centric-image-retrieval_amd", "hair_retrieval.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    a = cli.parse_args([])
+    assert (a.model_name, a.batch_size, a.num_workers, a.device, a.embed_save_dir, a.query_image, a.top_k,
+            a.num_queries, a.save_visualization, a.vis_save_dir, a.random_seed, a.extract_only, a.retrieve_only,
+            a.force_extract) == ("vit_base_patch16", 64, 8, None, "save/embeddings", None, 5, 5, False,
+                                 "save/visualizations", 42, False, False, False)
+    with pytest.raises(SystemExit):
+        cli.parse_args(["--model_name", "resnet50"])
+    from hcir.hair_encoder import ImageFolder, resize_shorter_side
+    win = np.load(os.path.join(golden_dir, "asset_windows.npz"))["windows"]
+    for cls, names in (("b_cls", ["z.png", "a.jpg"]), ("a_cls", ["m.png", "notes.txt"])):
+        os.makedirs(tmp_path / cls)
+        for i, n in enumerate(names):
+            if n.endswith(".txt"):
+                (tmp_path / cls / n).write_text("x")
+            else:
+                Image.fromarray(win[i]).save(tmp_path / cls / n)
+    ds = ImageFolder(str(tmp_path))
+    assert ds.classes == ["a_cls", "b_cls"]
+    assert [(os.path.relpath(p, tmp_path), c) for p, c in ds.samples] == [
+        ("a_cls/m.png", 0), ("b_cls/a.jpg", 1), ("b_cls/z.png", 1)]
+    assert resize_shorter_side(Image.new("RGB", (640, 301)), 224).size == (int(224 * 640 / 301), 224)
+    assert resize_shorter_side(Image.new("RGB", (100, 333)), 224).size == (224, int(224 * 333 / 100))
+    assert resize_shorter_side(Image.new("RGB", (224, 500)), 224).size == (224, 500)
+
+
+def test_topk_record_pack_roundtrip():
+    """One collective carries (fp32 value, int64 index) as an int32 record [Q, 3k] (hcir.dist.pack_topk)."""
+    from hcir.dist import pack_topk, unpack_topk
+    val = torch.tensor([[1.5, -0.0, float("-inf")], [3e-39, -2.25, float("inf")]])
+    idx = torch.tensor([[0, 2 ** 40 + 7, -1], [999_999, 2 ** 31, -1]], dtype=torch.int64)
+    rec = pack_topk(val, idx)
+    assert rec.dtype == torch.int32 and tuple(rec.shape) == (2, 9)
+    v2, i2 = unpack_topk(torch.stack([rec, rec], 0), 3)
+    assert v2.shape == (2, 2, 3) and torch.equal(i2[1], idx)
+    assert torch.equal(v2[0].view(torch.int32), val.view(torch.int32))     # bit-for-bit, -0.0 and denormals kept

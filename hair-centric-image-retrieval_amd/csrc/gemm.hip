@@ -613,6 +613,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
   WaveAcc<MF16> acc;
   acc.zero();
 
+#ifdef HCIR_GEMM_SKEW_CLK
+  // EXPERIMENT (build flag): every other workgroup of an XCD starts half a tile late, so that the epilogue
+  // store bursts of the two halves of an XCD's CUs do not coincide
+  if ((blockIdx.x >> 3) & 1) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    const uint64_t wait = (uint64_t)HCIR_GEMM_SKEW_CLK * (uint64_t)nkc;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+
   if (nsteps > 0) {
     set_sources(0);
 #pragma unroll
@@ -697,6 +707,377 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       ++ti;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Mid-tile GEMM: 128(n) x 192(m) per workgroup of FOUR waves (2 x 2, wave tile 64 x 96 = 4 x 6 MFMA 16x16x32
+// tiles, 96 accumulator registers), 2 x 40 KB LDS slots -> TWO workgroups per CU (2 x 80 KB = the CU's 160 KB).
+//
+// Why: the 256 x 256 kernel runs ONE workgroup per CU, so a CU's matrix pipes idle for the whole epilogue of
+// every tile (22 % of the launch at K = 768: LDS transposition, bias / GELU / LayerNorm-fold math, 128 KB of
+// stores per tile, all CUs at the same moment).  Two independent workgroups per CU fall into anti-phase by
+// themselves: while one transposes and stores, the other owns the matrix pipes, and the output bursts of a CU
+// (and of the chip) spread over the tile time.  Price: 1.67 x the L2->LDS bytes per flop of the 256^2 tile and
+// 10 instead of 12 fragment reads per 24 instead of 32 MFMAs (+11 % LDS reads per MFMA).
+// Same staging (LDS-DMA, 128-B rows, XOR swizzle), same MFMA operand maps and k order as the 256^2 kernel:
+// results are bit-identical to it.  Requires K % 64 == 0, N % 128 == 0.
+// ---------------------------------------------------------------------------
+struct GMid {
+  static constexpr int NT = 256;
+  static constexpr int TN = 128, TM = 192;
+  static constexpr int ROWS = TN + TM;             // 128 W rows (n) then 192 activation rows (m)
+  static constexpr int STAGE_BYTES = ROWS * 128;   // 40 KB
+  static constexpr int NLOAD = ROWS * 8 / NT;      // 10 pieces of 16 B per thread per stage (4 W + 6 activation)
+  static constexpr int NW = TN * 8 / NT;           // 4
+};
+
+// Epilogue of a 16x16x32 accumulator block acc[NTW n-tiles][.. MTH m-tiles from mt0]: (16 NTW) features x (16 MTH)
+// rows, transposed through `region` (16 MTH rows x 128 B, private to the wave) one 128-B output line per row and
+// pass; the arithmetic of gemm_epilogue256_lds_impl (same order of operations -> same bits).
+template <int EPI, bool FULL, int NTW, int MTT, int MTH>
+__device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, const f32x4 (&acc)[NTW][MTT], int mt0,
+                                                         char* region, int64_t m0h, int nbase, int lane) {
+  constexpr bool kLn = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  constexpr bool kGelu = (EPI == HCIR_EPI_BIAS_GELU_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  constexpr bool kResidH = (EPI == HCIR_EPI_BIAS_RESID_F16 || EPI == EPI_RESID_F16_STATS);
+  constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || kGelu || kLn || EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH);
+  constexpr bool kAffine = (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32);
+  constexpr int FPP = kF16 ? 64 : 32;      // features per pass = one 128-B line per row
+  constexpr int NPASS = NTW * 16 / FPP;
+  constexpr int NB = kF16 ? 2 : 1;
+  constexpr int NIT = MTH * 2;             // groups of 8 rows
+  constexpr int UB = (NIT % 4 == 0) ? 4 : 3;
+  static_assert(NIT % UB == 0 && (NTW * 16) % FPP == 0, "geometry");
+  const int rrow = lane >> 3, rchunk = lane & 7;
+  const int r16 = lane & 15, q16 = lane >> 4;
+
+  f32x4 bias[NPASS][NB], scale[NPASS][NB];
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = nbase + pass * FPP + rchunk * (kF16 ? 8 : 4) + 4 * j;
+      bias[pass][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      scale[pass][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (g.bias) bias[pass][j] = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if (kAffine || ((EPI == HCIR_EPI_BIAS_RESID_F32 || kResidH) && g.scale))
+        scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
+    }
+  }
+  float ln_rs[NIT], ln_mean[MTH];
+  f32x4 c1a[NTW];
+  if constexpr (kLn) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int64_t mm = m0h + it * 8 + rrow;
+      mm = mm < g.m ? mm : g.m - 1;
+      ln_rs[it] = g.ln_stats[2 * mm + 1];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTH; ++mt) {
+      int64_t mm = m0h + 16 * mt + r16;
+      mm = mm < g.m ? mm : g.m - 1;
+      ln_mean[mt] = g.ln_stats[2 * mm];
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) c1a[t] = *reinterpret_cast<const f32x4*>(g.ln_c1 + nbase + 16 * t + 4 * q16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (kLn) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(ln_rs[it]));
+#pragma unroll
+    for (int mt = 0; mt < MTH; ++mt) asm volatile("" : "+v"(ln_mean[mt]));
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) launder(c1a[t]);
+  }
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      launder(bias[pass][j]);
+      launder(scale[pass][j]);
+    }
+
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // ---- accumulators -> LDS (lane = output row m, registers = features n)
+#pragma unroll
+    for (int mt = 0; mt < MTH; ++mt) {
+      const int row = mt * 16 + r16;
+      if constexpr (kF16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nt = 4 * pass + q;
+          f16x4 o;
+          if constexpr (kLn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)__builtin_fmaf(-ln_mean[mt], c1a[nt][e], acc[nt][mt0 + mt][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[nt][mt0 + mt][e];
+          }
+          const int chunk = 2 * q + (q16 >> 1);
+          *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int nt = 2 * pass + q;
+          const int chunk = 4 * q + q16;
+          *reinterpret_cast<f32x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4)) = acc[nt][mt0 + mt];
+        }
+      }
+    }
+    // ---- LDS -> rows: lane = (row rrow + 8 it, 16-B chunk rchunk)
+    if constexpr (kF16) {
+      const int n = nbase + pass * 64 + rchunk * 8;
+#pragma unroll
+      for (int it0 = 0; it0 < NIT; it0 += UB) {
+        f16x8 oldh[UB];
+        if constexpr (kResidH) {
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int64_t mm = m0h + (it0 + u) * 8 + rrow;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oldh[u][e] = (_Float16)0.f;
+            if (FULL || mm < g.m)
+              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.out) + mm * g.ldo + n);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int row = (it0 + u) * 8 + rrow;
+          const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          f16x8 o;
+          float xs[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = (float)v[e];
+            const float bb = bias[pass][e >> 2][e & 3];
+            if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+              x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
+            } else if constexpr (kResidH) {
+              x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
+            } else if constexpr (kLn) {
+              x = __builtin_fmaf(ln_rs[it0 + u], x, bb);
+            } else {
+              x += bb;
+            }
+            xs[e] = x;
+          }
+          if constexpr (kGelu) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
+              xs[e] = y[0];
+              xs[e + 1] = y[1];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)xs[e];
+          const int64_t m = m0h + row;
+          if (FULL || m < g.m)
+            __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n));
+          if constexpr (EPI == EPI_RESID_F16_STATS) {
+            float xv[8], s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              xv[e] = (float)o[e];
+              s1 += xv[e];
+            }
+            const float mean_s = sum8_dpp(s1) * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float dv = xv[e] - mean_s;
+              m2 = __builtin_fmaf(dv, dv, m2);
+            }
+            m2 = sum8_dpp(m2);
+            if (rchunk == 0 && (FULL || m < g.m)) {
+              const int64_t slice = (nbase >> 6) + pass;
+              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){mean_s, m2};
+            }
+          }
+        }
+      }
+    } else {
+      const int n = nbase + pass * 32 + rchunk * 4;
+      const f32x4 b = bias[pass][0], sc = scale[pass][0];
+#pragma unroll
+      for (int it0 = 0; it0 < NIT; it0 += UB) {
+        f32x4 oldv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int64_t mm = m0h + (it0 + u) * 8 + rrow;
+          oldv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+            if (FULL || mm < g.m)
+              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int row = (it0 + u) * 8 + rrow;
+          const int64_t mm = m0h + row;
+          f32x4 v = *reinterpret_cast<const f32x4*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          if constexpr (EPI == HCIR_EPI_AFFINE_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], b[e]);
+          } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(sc[e], v[e] + b[e], oldv[u][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+          }
+          if (FULL || mm < g.m) *reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + mm * g.ldo + n) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_mid_kernel(GemmArgs g, int tiles_n, int tiles_m) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * GMid::STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_n = wave >> 1, wave_m = wave & 1;
+  const int ntiles = tiles_n * tiles_m;
+  const int nkc = g.k / 64;
+  const int my_tiles =
+      (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nsteps = my_tiles * nkc;
+
+  auto tile_origin = [&](int ti, int& n0, int64_t& m0) {
+    const int t = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
+    n0 = (t % tiles_n) * GMid::TN;
+    m0 = (int64_t)(t / tiles_n) * GMid::TM;
+  };
+
+  uint32_t soff[GMid::NLOAD];
+  const char* wbase = nullptr;
+  const char* abase = nullptr;
+  auto set_sources = [&](int t_i) {
+    int n0;
+    int64_t m0;
+    tile_origin(t_i, n0, m0);
+    wbase = reinterpret_cast<const char*>(g.w + (int64_t)n0 * g.ldw);
+    abase = reinterpret_cast<const char*>(g.a + m0 * g.lda);
+#pragma unroll
+    for (int i = 0; i < GMid::NLOAD; ++i) {
+      const int piece = tid + GMid::NT * i;
+      const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
+      if (row < GMid::TN) {
+        const int nr = n0 + row > g.n - 1 ? g.n - 1 - n0 : row;
+        soff[i] = (uint32_t)(((int64_t)nr * g.ldw + chunk * 8) * 2);
+      } else {
+        int64_t mr = row - GMid::TN;
+        mr = m0 + mr > g.m - 1 ? g.m - 1 - m0 : mr;
+        soff[i] = (uint32_t)((mr * g.lda + chunk * 8) * 2);
+      }
+    }
+  };
+  int issue_ti = 0, issue_kc = 0;
+  auto issue_piece = [&](int slot, int i) {  // i constant after unrolling: pieces 0..3 W rows, 4..9 activation rows
+    const char* sp = (i < GMid::NW ? wbase : abase) + issue_kc * 128 + soff[i];
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)sp,
+        (__attribute__((address_space(3))) void*)(lds + slot * GMid::STAGE_BYTES + ((tid & ~63) + GMid::NT * i) * 16),
+        16, 0, 0);
+  };
+  auto issue_advance = [&]() {
+    if (++issue_kc == nkc) {
+      issue_kc = 0;
+      ++issue_ti;
+      if (issue_ti < my_tiles) set_sources(issue_ti);
+    }
+  };
+
+  f32x4 acc[4][6];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 6; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  if (nsteps > 0) {
+    set_sources(0);
+#pragma unroll
+    for (int i = 0; i < GMid::NLOAD; ++i) issue_piece(0, i);
+    issue_advance();
+  }
+
+  const int r16 = lane & 15, kq = lane >> 4;
+  int kc = 0, ti = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const char* st = lds + (step & 1) * GMid::STAGE_BYTES;
+    const bool do_issue = step + 1 < nsteps;
+    const int islot = (step + 1) & 1;
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const int chunk = 4 * ks2 + kq;
+      u32x4 bf[6], af[4];
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt)
+        bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(GMid::TN + wave_m * 96 + mt * 16 + r16, chunk));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        af[q] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_n * 64 + q * 16 + r16, chunk));
+#pragma unroll
+      for (int hq = 0; hq < 2; ++hq) {
+        if (do_issue && ks2 == 0) {  // the ten DMA pieces of stage step+1 in the first 32-k substep
+#pragma unroll
+          for (int i = 0; i < 5; ++i) issue_piece(islot, 5 * hq + i);
+        }
+#pragma unroll
+        for (int q = 2 * hq; q < 2 * hq + 2; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 6; ++mt)
+            acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[q]),
+                                                               __builtin_bit_cast(f16x8, bf[mt]), acc[q][mt], 0, 0, 0);
+      }
+    }
+    if (do_issue) issue_advance();
+
+    if (++kc == nkc) {
+      int n0;
+      int64_t m0;
+      tile_origin(ti, n0, m0);
+      // every wave is done reading slot step&1; it stays free until the DMA of stage step+2 goes out behind the
+      // next step's barrier.  Per wave a private 6 KB piece of it: 48 rows x 128 B, two row halves per tile.
+      __builtin_amdgcn_s_barrier();
+      char* region = lds + (step & 1) * GMid::STAGE_BYTES + wave * 6144;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));  // opaque: the epilogue's addresses are not hoisted out of the tile loop
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int64_t m0h = m0 + wave_m * 96 + hh * 48;
+        if (m0h + 48 <= g.m)
+          gemm_epilogue16_lds_impl<EPI, true, 4, 6, 3>(g, acc, 3 * hh, region, m0h, n0 + wave_n * 64, lane_o);
+        else
+          gemm_epilogue16_lds_impl<EPI, false, 4, 6, 3>(g, acc, 3 * hh, region, m0h, n0 + wave_n * 64, lane_o);
+      }
+      zero_acc();
+      kc = 0;
+      ++ti;
+    }
+  }
+}
+
+inline bool gemm_takes_mid(int64_t m, int n, int k) { return k % 64 == 0 && m >= 1024 && n % 128 == 0; }
+
+template <int EPI>
+void launch_gemm_mid(const GemmArgs& g, hipStream_t st) {
+  const int tn = g.n / GMid::TN, tm = (int)hcir_cdiv(g.m, GMid::TM);
+  const int grid = tn * tm < 512 ? tn * tm : 512;  // persistent: two workgroups per CU
+  hipLaunchKernelGGL((gemm_f16_mid_kernel<EPI>), dim3(grid), dim3(256), 0, st, g, tn, tm);
 }
 
 // ---------------------------------------------------------------------------
@@ -885,7 +1266,16 @@ __global__ void cls_row_kernel(const float* __restrict__ cls, const float* __res
 inline bool gemm_takes_big(int64_t m, int n, int k) { return k % 64 == 0 && m >= 1024 && n % 256 == 0; }
 
 template <int EPI>
+void launch_gemm_mid(const GemmArgs& g, hipStream_t st);
+
+template <int EPI>
 void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
+#ifdef HCIR_GEMM_MID
+  if (g.n % 128 == 0) {   // EXPERIMENT (build flag): every persistent-kernel shape on the 2-workgroups-per-CU kernel
+    launch_gemm_mid<EPI>(g, st);
+    return;
+  }
+#endif
   const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
   const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
   // MFMA shape: a BUILD flag (make CXXFLAGS+=-DHCIR_GEMM_MFMA32 builds the 32x32x16 variant for A/B runs through

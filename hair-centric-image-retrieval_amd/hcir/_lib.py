@@ -74,6 +74,22 @@ class HcirError(RuntimeError):
     pass
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.h,
+    include/hcir.h), in sorted name order.  Recorded next to every PMC traffic summary under profiles/ so that
+    bench.py can tell a summary of THIS build from a stale one."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.h")))
+    files.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "hcir.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = False) -> str:
     """Compile libhcir.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC_DIR, "-j", str(min(8, os.cpu_count() or 1))]

@@ -5,7 +5,9 @@ usage: python3 tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in
 KB; FETCH_SIZE reports half of wide coalesced reads -> read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
 """
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hair-centric-image-retrieval_amd"))
 
 
 def load(d, counter):
@@ -58,6 +60,12 @@ def main():
                    "hits included. gemm_f16_big_kernel<0> first qkv, <8> LayerNorm-folded qkv, <9> LayerNorm-folded "
                    "fc1+GELU, <7> proj / fc2 with row statistics, <6> plain fp16-residual epilogue.",
            "kernels": kernels, "gemm_f16_big_kernel_avg_bytes_per_launch": int(avg)}
+    try:  # which build these counters belong to (bench.py reports them only for the same sources)
+        from hcir._lib import source_hash
+        res["src_hash"] = source_hash()
+    except Exception as e:  # noqa: BLE001
+        res["src_hash"] = None
+        print("source hash unavailable:", e)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v["bytes_per_launch"] for k, v in kernels.items()}, indent=1))
     print("gemm avg bytes/launch", int(avg))

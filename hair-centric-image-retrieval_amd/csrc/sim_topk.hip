@@ -621,6 +621,8 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
     hd[j] = 0;
     fetch(lane + 64 * j, 0, cv[j], ci[j]);
   }
+  float keep_v = kNegInf;
+  int64_t keep_i = -1;
   for (int o = 0; o < a.kout; ++o) {
     float bv = cv[0];
     int64_t bi = ci[0];
@@ -646,13 +648,21 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(MergeArgs<IdxT> a) {
       wi = take ? oi : wi;
       wl = take ? ol : wl;
     }
-    if (lane == 0) {
-      a.out_val[qi * a.kout + o] = wv;
-      if (a.out_idx) a.out_idx[qi * a.kout + o] = wi < 0 ? -1 : wi + a.idx_base;
-      if (a.out_idx32) a.out_idx32[qi * a.kout + o] = (int)wi;
-      if (o == a.kout - 1) {
-        if (a.kth_val) a.kth_val[qi] = wi < 0 ? kNegInf : wv;
-        if (a.kth_idx) a.kth_idx[qi] = (int)wi;
+    // winner o kept by lane o & 63, stored once per 64 rounds (see topk_merge32_kernel: no store inside the loop)
+    if (lane == (o & 63)) {
+      keep_v = wv;
+      keep_i = wi;
+    }
+    if ((o & 63) == 63 || o == a.kout - 1) {
+      const int oo = (o & ~63) + lane;
+      if (oo <= o) {
+        a.out_val[qi * a.kout + oo] = keep_i < 0 ? kNegInf : keep_v;
+        if (a.out_idx) a.out_idx[qi * a.kout + oo] = keep_i < 0 ? -1 : keep_i + a.idx_base;
+        if (a.out_idx32) a.out_idx32[qi * a.kout + oo] = (int)keep_i;
+        if (oo == a.kout - 1) {
+          if (a.kth_val) a.kth_val[qi] = keep_i < 0 ? kNegInf : keep_v;
+          if (a.kth_idx) a.kth_idx[qi] = (int)keep_i;
+        }
       }
     }
     if (lane == wl && wi >= 0) {
@@ -751,6 +761,11 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
     used[j] = 0;
     fetch4(lane + 64 * j, 0, kq[j]);
   }
+  // Winner o is KEPT by lane o and the whole result leaves after the loop, 64 outputs per store instruction.
+  // (With lane 0 storing inside the loop hipcc put `s_waitcnt vmcnt(0)` in front of every round - the refill
+  // load below shares the counter - so each of the k rounds waited for a store round trip: ~1.1 us per round,
+  // 18-23 us per merge of 16 ranks and 55 us per merge of 50; k <= 64 per pass, so one register holds it.)
+  uint64_t mine = 0ull;
   for (int o = 0; o < a.kout; ++o) {
     uint64_t best = kq[0][0];
     int bj = 0;
@@ -761,16 +776,20 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
       bj = take ? j : bj;
     }
     const uint64_t wm = wave_max_u64(best);
-    if (lane == 0) {
-      const bool none = wm == 0ull;
-      const float wv = none ? kNegInf : merge_key_val(wm);
-      const int wi = none ? -1 : merge_key_idx(wm);
-      a.out_val[qi * a.kout + o] = wv;
-      if (a.out_idx) a.out_idx[qi * a.kout + o] = none ? -1 : (int64_t)wi + a.idx_base;
-      if (a.out_idx32) a.out_idx32[qi * a.kout + o] = wi;
-      if (o == a.kout - 1) {
-        if (a.kth_val) a.kth_val[qi] = wv;
-        if (a.kth_idx) a.kth_idx[qi] = wi;
+    mine = (lane == (o & 63)) ? wm : mine;
+    if ((o & 63) == 63 || o == a.kout - 1) {   // a full wave of results (kout > 64 only from hcir_topk_merge callers)
+      const int oo = (o & ~63) + lane;
+      if (oo <= o) {
+        const bool none = mine == 0ull;
+        const float wv = none ? kNegInf : merge_key_val(mine);
+        const int wi = none ? -1 : merge_key_idx(mine);
+        a.out_val[qi * a.kout + oo] = wv;
+        if (a.out_idx) a.out_idx[qi * a.kout + oo] = none ? -1 : (int64_t)wi + a.idx_base;
+        if (a.out_idx32) a.out_idx32[qi * a.kout + oo] = wi;
+        if (oo == a.kout - 1) {
+          if (a.kth_val) a.kth_val[qi] = wv;
+          if (a.kth_idx) a.kth_idx[qi] = wi;
+        }
       }
     }
     if (wm != 0ull && best == wm) {  // row indices are unique: exactly one lane and one list hold the winner

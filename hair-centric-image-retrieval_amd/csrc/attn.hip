@@ -30,6 +30,7 @@ struct AttnArgs {
   int t, h;
   int nq;               // query rows computed per (b, head): T, or fewer (CLS-only last layer: 1)
   float scale_log2e;
+  float* lse;           // optional [B][H][T]: log2 of the softmax denominator incl. the row maximum (training)
 };
 
 template <int NKT>
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    if (a.lse && h == 0 && q0 + r < a.nq)   // p = exp2(s * scale_log2e - lse): what hcir_attn_bwd recomputes P from
+      a.lse[(b * a.h + head) * (int64_t)a.t + q0 + r] = mxs + __builtin_amdgcn_logf(sum);
 
     // ---- O^T = V^T . P ----
     f32x16 oacc[2];
@@ -222,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
-                             float scale, int32_t nq, void* out, void* stream) {
+static int attn_fwd_launch(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale, int32_t nq,
+                           void* out, float* lse, void* stream) {
   HCIR_ENTER();
   if (!qkv || !out || b <= 0 || t <= 0 || h <= 0 || nq <= 0 || nq > t) return HCIR_ERR_INVALID;
   if (hd != 64 || t > 288) return HCIR_ERR_UNSUPPORTED;
   if (b * h > 0x7fffffff) return HCIR_ERR_INVALID;
   AttnArgs a{static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), t, h, nq,
-             scale * 1.44269504088896340736f};
+             scale * 1.44269504088896340736f, lse};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nqt = (t + 31) / 32;
   const dim3 grid((unsigned)(b * h));
@@ -249,4 +252,16 @@ extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, i
 #undef LAUNCH
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
+}
+
+extern "C" int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale, int32_t nq,
+                             void* out, void* stream) {
+  return attn_fwd_launch(qkv, b, t, h, hd, scale, nq, out, nullptr, stream);
+}
+
+// training forward: all T query rows, and the per-row log2-sum-exp for hcir_attn_bwd
+extern "C" int hcir_attn_fwd_lse(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale,
+                                 void* out, float* lse, void* stream) {
+  if (!lse) return HCIR_ERR_INVALID;
+  return attn_fwd_launch(qkv, b, t, h, hd, scale, t, out, lse, stream);
 }

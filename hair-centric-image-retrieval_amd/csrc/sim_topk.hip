@@ -91,9 +91,17 @@ struct ScanArgs {
   int d, k;
   int shared_stream;  // > 1 query block reads every gallery tile: keep the stream in L2 (no `nt`)
   const int* gate;    // optional device flag: the launch does nothing unless *gate != 0 (fallback of the big scan)
+  // candidate-append mode (template CAND): no lists; every score above the floor goes to the query's buffer
+  float* cand_val;    // [cap][nq]
+  int* cand_idx;      // [cap][nq]
+  int* cand_cnt;      // [nq]
+  int* overflow;      // [1]
+  int cap;
+  int floor_groups;   // floor = min over this many [nq] arrays behind floor_val (group floors of the prefix)
+  int floor_inclusive;  // 1: candidates are scores >= floor (the scan covers the rows the floor came from)
 };
 
-template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS>
+template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS, bool CAND = false>
 __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
   using Cfg = SimCfg<T, WGG, WQ, QT>;
   constexpr int EPS = SimElem<T>::kPerStage;
@@ -119,16 +127,17 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   const int64_t q_row0 = (int64_t)blockIdx.y * Cfg::QB;
   const int64_t q_last = a.nq - 1;
 
-  // per-lane query state
-  float lv[QT][KP];
-  int li[QT][KP];
+  // per-lane query state (CAND keeps no lists: one dummy entry)
+  constexpr int KL = CAND ? 1 : KP;
+  float lv[QT][KL];
+  int li[QT][KL];
   float thr[QT], qnv[QT], cval[QT];
   int cidx[QT];
   int64_t myq[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
-    for (int j = 0; j < KP; ++j) {
+    for (int j = 0; j < KL; ++j) {
       lv[qt][j] = kNegInf;
       li[qt][j] = -1;
     }
@@ -137,6 +146,12 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     const int64_t qc = live ? myq[qt] : q_last;
     qnv[qt] = a.qn ? a.qn[qc] : 1.0f;
     thr[qt] = a.floor_val ? a.floor_val[qc] : kNegInf;
+    if constexpr (CAND) {
+      // group floors of the prefix: every group holds >= k/groups rows at or above its floor, so the minimum
+      // is a valid floor for k; padding queries never match
+      for (int gidx = 1; gidx < a.floor_groups; ++gidx) thr[qt] = fminf(thr[qt], a.floor_val[gidx * a.nq + qc]);
+      if (!live) thr[qt] = __builtin_huge_valf();
+    }
     cval[qt] = a.ceil_val ? a.ceil_val[qc] : __builtin_huge_valf();
     cidx[qt] = a.ceil_val ? a.ceil_idx[qc] : -1;
   }
@@ -164,16 +179,62 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   // staging one stage ahead with zero fill past d.
   u32x4 regs[GLDS ? 1 : Cfg::NLOAD];
   auto tile_row0 = [&](int64_t ti) { return a.row_begin + ((int64_t)blockIdx.x + ti * gridDim.x) * Cfg::GM; };
+  // DMA sources as 32-bit per-lane byte offsets from a wave-uniform base (tile's first gallery row / block's first
+  // query row, + 128 B per k chunk): computed ONCE - they are the same for every full tile - so a stage issues
+  // NLOAD loads and nothing else.  (Re-deriving row, clamp and a 64-bit product per piece and stage cost ~300
+  // VALU instructions per stage: with one stage in flight per workgroup that was on the critical path of both the
+  // one-tile prefix workgroups and the streaming main scan.)  Only the gallery's last tile can be partial: its
+  // rows are clamped to the last row when the issue cursor reaches it (it is the last tile of its workgroup).
+  constexpr int NPG = Cfg::GM / 32, NPQ = Cfg::QB / 32;  // pieces of a stage: gallery rows, then query rows
+  static_assert(NPG + NPQ == Cfg::NLOAD, "pieces");
+  constexpr int EPC_ = SimElem<T>::kPerChunk;
+  uint32_t goff[NPG], qoff[NPQ];
+  auto set_goff = [&](int64_t rows_valid) {  // rows_valid >= GM: full tile
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      const int slot = tid + Cfg::NT * i;
+      int row = slot >> 3;
+      const int chunk = (slot & 7) ^ ((row >> 1) & 7);
+      row = row < rows_valid ? row : (int)rows_valid - 1;
+      goff[i] = (uint32_t)(((int64_t)row * a.d + chunk * EPC_) * (int64_t)sizeof(T));
+    }
+  };
+  if constexpr (GLDS) {
+    set_goff(Cfg::GM);
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i) {
+      const int slot = tid + Cfg::NT * (NPG + i);
+      const int row = (slot >> 3) - Cfg::GM;
+      const int chunk = (slot & 7) ^ (((slot >> 3) >> 1) & 7);
+      int64_t qr = q_row0 + row;
+      qr = qr > q_last ? q_last : qr;
+      qoff[i] = (uint32_t)(((qr - q_row0) * a.d + chunk * EPC_) * (int64_t)sizeof(T));
+    }
+  }
   // stage s of this workgroup = (tile s / nkc, chunk s % nkc); the issue cursor runs NST-1 stages ahead
   int64_t issue_tile = 0;
   int issue_kc = 0;
   auto issue_stage = [&](int slot) {
-    if (a.shared_stream)
-      sim_stage_glds<T, Cfg, 0>(lds + slot * Cfg::STAGE_BYTES, g, tile_row0(issue_tile), g_last, q, q_row0, q_last,
-                                a.d, issue_kc, tid);
-    else
-      sim_stage_glds<T, Cfg, HCIR_SCAN_AUX>(lds + slot * Cfg::STAGE_BYTES, g, tile_row0(issue_tile), g_last, q,
-                                            q_row0, q_last, a.d, issue_kc, tid);
+    const int64_t r0 = tile_row0(issue_tile);
+    if (issue_kc == 0 && r0 + Cfg::GM > a.row_end) set_goff(a.row_end - r0);
+    const char* gb = reinterpret_cast<const char*>(g) + (r0 * a.d) * (int64_t)sizeof(T) + issue_kc * 128;
+    const char* qb = reinterpret_cast<const char*>(q) + (q_row0 * a.d) * (int64_t)sizeof(T) + issue_kc * 128;
+    char* dst = lds + slot * Cfg::STAGE_BYTES + (tid & ~63) * 16;
+#pragma unroll
+    for (int i = 0; i < NPG; ++i) {
+      if (a.shared_stream)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + goff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + Cfg::NT * i * 16), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + goff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + Cfg::NT * i * 16), 16, 0,
+                                         HCIR_SCAN_AUX);
+    }
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + qoff[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + Cfg::NT * (NPG + i) * 16), 16,
+                                       0, 0);
     if (++issue_kc == nkc) {
       issue_kc = 0;
       ++issue_tile;
@@ -250,6 +311,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
             if (a.qn) s = s * qnv[qt];
             acc[gt][qt][i] = s;
             bool cand = (row < a.row_end) && (s > thr[qt]);
+            if constexpr (CAND) cand = cand || ((row < a.row_end) && a.floor_inclusive && s == thr[qt]);
             if (a.ceil_val)
               cand = cand && ((s < cval[qt]) || (s == cval[qt] && (int)row > cidx[qt]));
             mask |= cand ? (1u << i) : 0u;
@@ -268,9 +330,21 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
             const int i = __builtin_ctz(any);
             any &= any - 1u;
             const float s = acc[gt][qt][i];
-            if (((mask >> i) & 1u) && s > thr[qt]) {
-              topk_insert<KP>(lv[qt], li[qt], s, (int)(rbase + (i & 3) + 8 * (i >> 2)));
-              thr[qt] = fmaxf(floorv[qt], topk_kth<KP>(lv[qt], a.k));
+            if constexpr (CAND) {
+              if ((mask >> i) & 1u) {  // rare behind the floor: one global atomic per candidate
+                const int pos = atomicAdd(a.cand_cnt + myq[qt], 1);
+                if (pos < a.cap) {
+                  a.cand_val[(int64_t)pos * a.nq + myq[qt]] = s;
+                  a.cand_idx[(int64_t)pos * a.nq + myq[qt]] = (int)(rbase + (i & 3) + 8 * (i >> 2));
+                } else {
+                  *a.overflow = 1;
+                }
+              }
+            } else {
+              if (((mask >> i) & 1u) && s > thr[qt]) {
+                topk_insert<KP>(lv[qt], li[qt], s, (int)(rbase + (i & 3) + 8 * (i >> 2)));
+                thr[qt] = fmaxf(floorv[qt], topk_kth<KP>(lv[qt], a.k));
+              }
             }
           }
 #pragma unroll
@@ -283,6 +357,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     tile_i = ntile_i;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
+  if constexpr (!CAND) {  // (CAND: nothing to merge, the candidates are already in the per-query buffers)
   __syncthreads();  // every wave is done with the stage buffers before they are re-used below
 
   // ---- merge the NSRC lists of each query through LDS, one thread per query,
@@ -359,6 +434,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     }
     __syncthreads();
   }
+  }  // !CAND
 }
 
 // --------------------------------------------------------------------------
@@ -579,6 +655,8 @@ struct MergeArgs {
   const int* gate;       // optional device flag: run only if (*gate != 0) == (gate_want != 0)
   int gate_want;
   int* zero_cnt;         // optional [nq + 1]: cleared here (candidate counters + overflow flag of the big scan)
+  int ngroups;           // > 1: blockIdx.y = group g merges lists g, g + ngroups, ... into out[g][nq][kout],
+                         //      kth_val[g][nq] (group floors of the prefix); 0 / 1: one group
 };
 
 template <typename IdxT, int LPL = kMergeLPL>
@@ -717,14 +795,16 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
   const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qi >= a.nq) return;
   if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
-  if (a.zero_cnt && lane == 0) {
+  const int ng_ = a.ngroups > 1 ? a.ngroups : 1, grp = (int)blockIdx.y;
+  if (a.zero_cnt && lane == 0 && grp == 0) {
     a.zero_cnt[qi] = 0;
     if (qi == 0) a.zero_cnt[a.nq] = 0;
   }
   const bool has_extra = a.extra_val != nullptr;
-  int nl = a.nlists;
+  int nl = (a.nlists - grp + ng_ - 1) / ng_;   // lists of this group
   if (a.nlists_q) nl = a.nlists_q[qi] < nl ? a.nlists_q[qi] : nl;
-  const int extra_list = a.nlists;  // list index of the optional extra list
+  const int extra_list = nl;  // list index of the optional extra list
+  const int64_t gout = (int64_t)grp * a.nq;   // output row offset of the group
 
   // entries [pos, pos + 4) of a list as keys (0 where the list has ended)
   auto fetch4 = [&](int list, int pos, uint64_t (&k4)[4]) {
@@ -734,8 +814,8 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
     const int* pi = nullptr;
     int len = 0;
     if (list < nl) {
-      pv = a.vals + ((int64_t)list * a.nq + qi) * a.kin;
-      pi = a.idx + ((int64_t)list * a.nq + qi) * a.kin;
+      pv = a.vals + ((int64_t)(list * ng_ + grp) * a.nq + qi) * a.kin;
+      pi = a.idx + ((int64_t)(list * ng_ + grp) * a.nq + qi) * a.kin;
       len = a.kin;
     } else if (has_extra && list == extra_list) {
       pv = a.extra_val + qi * a.kin_extra;
@@ -783,12 +863,12 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
         const bool none = mine == 0ull;
         const float wv = none ? kNegInf : merge_key_val(mine);
         const int wi = none ? -1 : merge_key_idx(mine);
-        a.out_val[qi * a.kout + oo] = wv;
-        if (a.out_idx) a.out_idx[qi * a.kout + oo] = none ? -1 : (int64_t)wi + a.idx_base;
-        if (a.out_idx32) a.out_idx32[qi * a.kout + oo] = wi;
+        a.out_val[(gout + qi) * a.kout + oo] = wv;
+        if (a.out_idx) a.out_idx[(gout + qi) * a.kout + oo] = none ? -1 : (int64_t)wi + a.idx_base;
+        if (a.out_idx32) a.out_idx32[(gout + qi) * a.kout + oo] = wi;
         if (oo == a.kout - 1) {
-          if (a.kth_val) a.kth_val[qi] = wv;
-          if (a.kth_idx) a.kth_idx[qi] = wi;
+          if (a.kth_val) a.kth_val[gout + qi] = wv;
+          if (a.kth_idx) a.kth_idx[gout + qi] = wi;
         }
       }
     }
@@ -805,6 +885,63 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
         }
       }
     }
+  }
+}
+
+// --------------------------------------------------------------------------
+// select: top-k of an UNSORTED candidate buffer (what the candidate-append scans leave: [cap][nq], cnt[nq]) plus an
+// optional sorted list per query (the prefix result).  One wave per query, every entry a 64-bit (score, ~row) key
+// in a register (lane l owns candidates l, l + 64, ...; its last slot takes entry l of the sorted list); k rounds
+// of wave maximum, the winner's slot cleared by key equality (row indices are unique).  No list heads to
+// advance, no loads or stores inside the loop.  cap = 64 (LPL - 1).
+// --------------------------------------------------------------------------
+struct SelectArgs {
+  const float* cand_val;
+  const int* cand_idx;
+  const int* cand_cnt;
+  int cap;
+  const float* pre_val;  // optional [nq][kpre], sorted
+  const int* pre_idx;
+  int kpre;
+  float* out_val;
+  int64_t* out_idx;
+  int64_t nq, idx_base;
+  int k;
+  const int* gate;       // run only if (*gate != 0) == (gate_want != 0)
+  int gate_want;
+};
+
+template <int LPL>
+__global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= a.nq) return;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  int cnt = a.cand_cnt[qi];
+  cnt = cnt < a.cap ? cnt : a.cap;
+  uint64_t kq[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL - 1; ++j) {
+    const int e = lane + 64 * j;
+    kq[j] = 0ull;
+    if (e < cnt) kq[j] = merge_key(a.cand_val[(int64_t)e * a.nq + qi], a.cand_idx[(int64_t)e * a.nq + qi]);
+  }
+  kq[LPL - 1] = 0ull;
+  if (a.pre_val && lane < a.kpre) kq[LPL - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
+  uint64_t mine = 0ull;
+  for (int o = 0; o < a.k; ++o) {
+    uint64_t best = kq[0];
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) best = kq[j] > best ? kq[j] : best;
+    const uint64_t wm = wave_max_u64(best);
+    mine = (lane == o) ? wm : mine;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) kq[j] = (kq[j] == wm) ? 0ull : kq[j];
+  }
+  if (lane < a.k) {
+    const bool none = mine == 0ull;
+    a.out_val[qi * a.k + lane] = none ? kNegInf : merge_key_val(mine);
+    a.out_idx[qi * a.k + lane] = none ? -1 : (int64_t)merge_key_idx(mine) + a.idx_base;
   }
 }
 
@@ -934,6 +1071,11 @@ Plan make_plan(int64_t nq, int64_t ng, int k) {
 // to the prefix list
 constexpr int kCandLPL = 16;
 constexpr int kCandCap = 64 * kCandLPL - 64;  // 960
+// candidate-append scans of <= 128 queries with 16 < k <= 64: the floor is the minimum of ceil(k/16) group floors
+// (weaker than one k-th score), so more rows clear it
+constexpr int kSelLPLBig = 48;
+constexpr int kCandCapBig = 64 * kSelLPLBig - 64;  // 3008
+constexpr int kMaxFloorGroups = 4;
 
 struct Workspace {
   float* part_val;
@@ -963,13 +1105,13 @@ Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
   w.part_idx = reinterpret_cast<int*>(take(part * 4));
   w.pre_val = reinterpret_cast<float*>(take((size_t)nq * p.kp * 4));
   w.pre_idx = reinterpret_cast<int*>(take((size_t)nq * p.kp * 4));
-  w.floor_val = reinterpret_cast<float*>(take((size_t)nq * 4));
+  w.floor_val = reinterpret_cast<float*>(take((size_t)nq * 4 * kMaxFloorGroups));
   w.ceil_val = reinterpret_cast<float*>(take((size_t)nq * 4));
   w.ceil_idx = reinterpret_cast<int*>(take((size_t)nq * 4));
-  w.cand_val = reinterpret_cast<float*>(take((size_t)kCandCap * nq * 4));
-  w.cand_idx = reinterpret_cast<int*>(take((size_t)kCandCap * nq * 4));
+  const size_t ccap = (k > 16 && k <= 64 && nq <= 128) ? kCandCapBig : kCandCap;
+  w.cand_val = reinterpret_cast<float*>(take(ccap * nq * 4));
+  w.cand_idx = reinterpret_cast<int*>(take(ccap * nq * 4));
   w.cand_cnt = reinterpret_cast<int*>(take(((size_t)nq + 1) * 4));
-  (void)k;
   w.bytes = off;
   return w;
 }
@@ -1001,6 +1143,33 @@ void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
   } else {
     launch_scan_cfg<T, 16, 2, 2, 2>(a, grid_x, grid_y, st);
   }
+}
+
+// candidate-append scan (no lists): geometry by query count only
+template <typename T, int QT, int WQ, int WGG>
+void launch_cand_cfg(const ScanArgs& a, int grid_x, int grid_y, hipStream_t st) {
+  if (a.d % SimElem<T>::kPerStage == 0)
+    hipLaunchKernelGGL((sim_topk_scan<T, 16, QT, WQ, WGG, true, true>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((sim_topk_scan<T, 16, QT, WQ, WGG, false, true>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+}
+template <typename T>
+void launch_cand(int qb, const ScanArgs& a, int grid_x, hipStream_t st) {
+  const int grid_y = (int)hcir_cdiv(a.nq, qb);
+  if (qb == 32)
+    launch_cand_cfg<T, 1, 1, 4>(a, grid_x, grid_y, st);
+  else if (qb == 64)
+    launch_cand_cfg<T, 2, 1, 4>(a, grid_x, grid_y, st);
+  else
+    launch_cand_cfg<T, 2, 2, 2>(a, grid_x, grid_y, st);
+}
+void launch_cand_dtype(int dtype, int qb, const ScanArgs& a, int grid_x, hipStream_t st) {
+  if (dtype == HCIR_F32)
+    launch_cand<float>(qb, a, grid_x, st);
+  else if (dtype == HCIR_F16)
+    launch_cand<_Float16>(qb, a, grid_x, st);
+  else
+    launch_cand<__bf16>(qb, a, grid_x, st);
 }
 
 // -DHCIR_SCAN_NO_BIG (build flag) keeps the list-keeping scan for every query count (A/B libraries through
@@ -1061,7 +1230,122 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   a.d = d;
   a.shared_stream = qblocks > 1 ? 1 : 0;
 
+  // ---- <= 128 queries, k <= 64, big gallery: candidate-append flow (DESIGN.md "sim_topk: candidate flow").
+  //   A  rows [0, S): the 16-entry list kernel (its fixed cost is 53 us; the 64-entry one costs 131 us), workgroup
+  //      x in group x % G, G = 1 (k <= 16) or ceil(k / 16); one merge launch gives every group's floor - the
+  //      k-th (G = 1) or 16th best score of the group - and, for G = 1, the prefix top-k list;
+  //   B  a scan WITHOUT lists appends every row at / above the floor (min over the groups: >= k rows sit at or
+  //      above it) to the query's candidate buffer: G = 1 over rows [S, N) with `> floor` (a tie loses to the k
+  //      prefix rows with smaller indices), G > 1 over ALL rows with `>= floor` (the group lists do not hold the
+  //      prefix's top-k);
+  //   C  select: top-k of the candidates (+ the prefix list), one wave per query.
+  // A gallery whose later rows systematically beat the prefix overflows a buffer: the device flag then gates the
+  // list-keeping flow below (all of it for G > 1, its second phase for G = 1), whose launches are empty otherwise.
+  const int* fallback_gate = nullptr;
+  bool prefix_done = false;
+  int64_t cand_prefix = 0;
+  if (p.npass == 1 && p.prefix < ng && nq <= 128) {
+    const int G = k <= 16 ? 1 : (k + 15) / 16;
+    int cap = k <= 16 ? kCandCap : kCandCapBig;
+    Plan pc = p;
+    pc.kp = 16;
+    pc.qb = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
+    pc.gm = pc.qb == 128 ? 128 : 256;
+    int64_t S = p.prefix;
+    if (G == 1) {
+      // Without lists behind the floor a longer prefix costs little (one round of <= 512 one-tile workgroups
+      // takes the same ~55 us as half a round) and pays twice: fewer rows for the main scan and r = 7 instead of
+      // 15, i.e. <= 38 * 7 candidates per query, a 7-slot select instead of a 15-slot one.
+      // (measured, 1 M x 768 fp16: 32 queries 0.314 -> 0.306 ms; at 64 queries the 2-tile-deep list prefix costs
+      // what the shorter main scan and select save, 0.330 -> 0.335 ms: N/16 kept there)
+      S = pc.qb == 32 ? ng / 8 : ng / 16;
+      S = S < 8192 ? 8192 : (S > 131072 ? 131072 : S);
+      S = hcir_cdiv(S, pc.gm) * pc.gm;
+      if (S < ng && 38 * ((ng - S) / S + 1) <= 64 * 7) cap = 64 * 7;  // small select (one buffer size for scan AND select)
+    }
+    if (G > 1) {
+      // Rows at or above the floor, r + 1 = N / S.  The tail probability at a group's 16th best of n rows is
+      // ~ Gamma(16) / n (mean 16, sd 4), the floor is the weakest of the G groups: the count is ~ X G (r + 1) with
+      // X the largest of G Gamma(16) draws.  P(X > 38) ~ 1e-5 per draw: sized for 38 G (r + 1) <= cap (an
+      // earlier 16 G + 5 sigma sizing overflowed a few percent of the QUERIES, and one overflow reruns the call).
+      const float per = 38.0f * G;
+      int64_t rp1 = (int64_t)((float)cap / per);
+      rp1 = rp1 < 2 ? 2 : rp1;
+      S = hcir_cdiv(ng, rp1);
+      S = S < 8192 ? 8192 : S;
+      S = hcir_cdiv(S, pc.gm) * pc.gm;
+    }
+    if (S < ng && hcir_cdiv(S, pc.gm) >= 4 * G) {
+      const int64_t qbl = hcir_cdiv(nq, pc.qb);
+      ScanArgs c = a;
+      c.shared_stream = qbl > 1 ? 1 : 0;
+      c.k = G == 1 ? k : 16;
+      c.row_begin = 0;
+      c.row_end = S;
+      const int grid_a = scan_grid_x(hcir_cdiv(S, pc.gm), qbl);
+      launch_scan_dtype(dtype, pc, c, grid_a, st);
+      HCIR_LAUNCH_CHECK();
+      MergeArgs<int> m{};
+      m.vals = w.part_val;
+      m.idx = w.part_idx;
+      m.nq = nq;
+      m.nlists = grid_a;
+      m.kin = 16;
+      m.kout = c.k;
+      m.out_val = w.pre_val;
+      m.out_idx32 = w.pre_idx;
+      m.kth_val = w.floor_val;
+      m.zero_cnt = w.cand_cnt;
+      m.ngroups = G;
+      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid, G), dim3(256), 0, st, m);
+      HCIR_LAUNCH_CHECK();
+      int* overflow = w.cand_cnt + nq;
+      c.row_begin = G == 1 ? S : 0;
+      c.row_end = ng;
+      c.floor_val = w.floor_val;
+      c.floor_groups = G;
+      c.floor_inclusive = G > 1 ? 1 : 0;
+      c.cand_val = w.cand_val;
+      c.cand_idx = w.cand_idx;
+      c.cand_cnt = w.cand_cnt;
+      c.overflow = overflow;
+      c.cap = cap;
+      const int grid_b = scan_grid_x(hcir_cdiv(c.row_end - c.row_begin, pc.gm), qbl);
+      launch_cand_dtype(dtype, pc.qb, c, grid_b, st);
+      HCIR_LAUNCH_CHECK();
+      SelectArgs sa{};
+      sa.cand_val = w.cand_val;
+      sa.cand_idx = w.cand_idx;
+      sa.cand_cnt = w.cand_cnt;
+      sa.cap = cap;
+      if (G == 1) {
+        sa.pre_val = w.pre_val;
+        sa.pre_idx = w.pre_idx;
+        sa.kpre = k;
+      }
+      sa.out_val = out_val;
+      sa.out_idx = out_idx;
+      sa.nq = nq;
+      sa.idx_base = idx_base;
+      sa.k = k;
+      sa.gate = overflow;
+      sa.gate_want = 0;
+      // expected candidates <= 38 (N - S) / S per query (k <= 16): a small select when the prefix is long
+      if (cap == 64 * 7)
+        hipLaunchKernelGGL(topk_select_kernel<8>, dim3(merge_grid), dim3(256), 0, st, sa);
+      else if (k <= 16)
+        hipLaunchKernelGGL(topk_select_kernel<kCandLPL>, dim3(merge_grid), dim3(256), 0, st, sa);
+      else
+        hipLaunchKernelGGL(topk_select_kernel<kSelLPLBig>, dim3(merge_grid), dim3(256), 0, st, sa);
+      HCIR_LAUNCH_CHECK();
+      fallback_gate = overflow;
+      prefix_done = G == 1;   // the list flow's phase A is exactly what ran above (same kernel, rows [0, S))
+      if (G == 1) cand_prefix = S;
+    }
+  }
+
   Plan pp = p;  // (the prefix may shrink below)
+  if (cand_prefix) pp.prefix = cand_prefix;
   // Many queries (MFMA-bound): the 256 x 256 tile scan collects the rare rows above the prefix floor.  The
   // prefix itself runs on the list-keeping kernel at half that rate, so it is only as long as the candidate
   // buffers require.  With r = rows behind the prefix / prefix rows, the number of rows that beat the
@@ -1087,9 +1371,14 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     a.row_end = pp.prefix;
     const int64_t tiles_a = hcir_cdiv(pp.prefix, p.gm);
     const int grid_a = scan_grid_x(tiles_a, qblocks);
-    launch_scan_dtype(dtype, p, a, grid_a, st);
-    HCIR_LAUNCH_CHECK();
+    a.gate = fallback_gate;
+    if (!prefix_done) {
+      launch_scan_dtype(dtype, p, a, grid_a, st);
+      HCIR_LAUNCH_CHECK();
+    }
     MergeArgs<int> m{};
+    m.gate = fallback_gate;
+    m.gate_want = 1;
     m.vals = w.part_val;
     m.idx = w.part_idx;
     m.nq = nq;
@@ -1108,8 +1397,10 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m.out_idx32 = w.pre_idx;
     m.kth_val = w.floor_val;
     if (big) m.zero_cnt = w.cand_cnt;  // the big scan's counters and overflow flag start at zero
-    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
-    HCIR_LAUNCH_CHECK();
+    if (!prefix_done) {
+      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
+      HCIR_LAUNCH_CHECK();
+    }
     // phase B: rows [prefix, ng) with the prefix k-th score as floor
     a.row_begin = pp.prefix;
     a.row_end = ng;
@@ -1180,6 +1471,9 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m2.idx_base = idx_base;
     if (big) {
       m2.gate = overflow;
+      m2.gate_want = 1;
+    } else if (fallback_gate) {
+      m2.gate = fallback_gate;
       m2.gate_want = 1;
     }
     hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m2);

@@ -63,6 +63,24 @@ SIGNATURES = {
     "hcir_positive_masking": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp,
                                       c_vp]),
     "hcir_convert_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "hcir_gelu_fwd_f16": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "hcir_gelu_bwd_f16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "hcir_add_f32_f16": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "hcir_layernorm_bwd_blocks": (c_i32, [c_i64]),
+    "hcir_layernorm_bwd": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
+                                   c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "hcir_colsum_chunks": (c_i32, [c_i64]),
+    "hcir_colsum_f16": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "hcir_gemm_f16_tn_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "hcir_gemm_f16_tn": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_int, c_vp, c_sz,
+                                 c_vp]),
+    "hcir_attn_fwd_lse": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "hcir_attn_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "hcir_triplet_margin_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "hcir_triplet_margin_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp]),
+    "hcir_mse_fwd": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "hcir_mse_bwd": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "hcir_knn_vote": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "hcir_confusion_matrix": (c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "hcir_retrieval_metrics": (c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,

@@ -8,8 +8,11 @@ signatures (HP/src/main_backbone.py:528-637), backed by the MI355X hot path.
 
 ViT compute goes through hcir.vit_engine -> libhcir.so (hand-written HIP);
 ResNet trunks are PyTorch-ROCm modules.  The ViT path has no CPU
-fallback and, in this round, no backward: calling it with autograd enabled on
-parameters that require grad raises NotImplementedError.
+fallback.  With autograd enabled on parameters that require grad, `forward_cls` runs the
+training forward of hcir.vit_train (activations kept, backward through hcir_gemm_f16_tn /
+hcir_attn_bwd / hcir_layernorm_bwd ...): `SHAM2.forward` in train mode is differentiable
+(HP/src/pretrain_engine.py:682-745).  `ViTWrapper.forward` (class token AND pooled patches) stays
+inference-only.
 """
 from __future__ import annotations
 
@@ -22,6 +25,7 @@ from . import _lib
 from ._lib import HcirError, check
 from . import _tv_resnet, _tv_vit
 from .vit_engine import EngineCache, VitLayer, VitSpec
+from .vit_train import VitTrainer, vit_cls_with_grad
 
 # The reference adds the positional embedding in ViTWrapper.forward AND again inside
 # torchvision's Encoder.forward (same Parameter): embeddings are LN(blocks(x + 2*pos)).
@@ -118,11 +122,23 @@ class ViTWrapper(nn.Module):
     def engine(self, device: torch.device):
         return self._cache.get(list(self.parameters()), self._spec, device)
 
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def _check_no_grad(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self._needs_grad():
             raise NotImplementedError(
-                "the HIP ViT path is forward-only this round: wrap the call in torch.no_grad() "
-                "(training backward is SURVEY.md §8f rank 3)")
+                "ViTWrapper.forward (class token + pooled patches) is inference-only on the HIP path: wrap the call "
+                "in torch.no_grad(), or use forward_cls / SHAM2.forward, which are differentiable")
+
+    def trainer(self, device: torch.device) -> VitTrainer:
+        """Training-side twin of `engine`: fp16 operand copies (as stored and transposed) refreshed when a
+        parameter's version changes (optimizer step), activations kept per forward."""
+        tr = getattr(self, "_trainer", None)
+        if tr is None or tr.device != device:
+            tr = VitTrainer(self._spec(), device)
+            self._trainer = tr
+        return tr
 
     def forward(self, x: torch.Tensor):
         self._check_no_grad()
@@ -134,8 +150,12 @@ class ViTWrapper(nn.Module):
 
     def forward_cls(self, x: torch.Tensor, l2_normalize: bool = False, want_f16: bool = False):
         """CLS embedding only (what SHAM2.extract_features consumes); optionally fused
-        F.normalize and an fp16 copy for the similarity scan."""
-        self._check_no_grad()
+        F.normalize and an fp16 copy for the similarity scan.  Differentiable when autograd is on and the
+        parameters require grad (then fp32 [B, D], no fused normalise)."""
+        if self._needs_grad():
+            if l2_normalize or want_f16:
+                raise NotImplementedError("the differentiable forward returns the plain fp32 class token")
+            return vit_cls_with_grad(self.trainer(x.device), x)
         eng = self.engine(x.device)
         tok = eng.forward_tokens(x, cls_only_last=True)   # only the class token is consumed
         return eng.cls_embedding(tok, final_norm=True, l2_normalize=l2_normalize, want_f16=want_f16)
@@ -173,8 +193,10 @@ class SHAM2(nn.Module):
 
     def _vit_project(self, backbone, head, x):
         if head.training:
-            raise NotImplementedError("SHAM2.forward in train mode through the HIP ViT is not built "
-                                      "yet (SURVEY.md §8f rank 3); call .eval() and torch.no_grad()")
+            # train mode (HP/src/pretrain_engine.py:603 model.train()): the backbone forward is differentiable on the
+            # HIP path (hcir.vit_train); the lightly head is torch modules as in the reference - BatchNorm1d with
+            # batch statistics and running-stat updates, autograd by torch (B x 768 x 768: 0.1 % of the step)
+            return head(backbone.forward_cls(x))
         _, cls16 = backbone.forward_cls(x, l2_normalize=False, want_f16=True)
         return head.forward_hip(cls16)
 

@@ -1,0 +1,259 @@
+"""hcir.vit_train — training-mode forward and backward of the ViT on MI355X through libhcir
+(the backbone half of `self.model(x)` + `.backward()` in
+HP/src/pretrain_engine.py:682-745).
+
+`VitTrainer.forward(x)` runs
+    patch_embed -> depth x [ LN1 -> qkv GEMM -> attention (+ log-sum-exp) -> proj GEMM + residual ->
+                             LN2 -> fc1 GEMM -> GELU -> fc2 GEMM + residual ] -> final LN of the class token
+keeping, per block, what the backward needs (fp16: block input, both LayerNorm outputs, qkv, attention output,
+fc1 pre-activation and activation; fp32: the attention's row log-sum-exp).  `VitTrainer.backward(saved, d_cls)`
+walks the blocks in reverse:
+    dgrad    dX = dY . W          hcir_gemm_f16 against a transposed fp16 copy of the weight
+    wgrad    dW = dY^T . X        hcir_gemm_f16_tn (operands as stored, transposed LDS reads, split-M, deterministic)
+    bias     db = colsum(dY)      hcir_colsum_f16
+    GELU', LayerNorm', attention' hcir_gelu_bwd_f16, hcir_layernorm_bwd, hcir_attn_bwd
+The residual gradient travels in fp32, GEMM operands in fp16 (a GradScaler's loss scale passes through linearly,
+as under the reference's fp16 autocast).  `vit_cls_with_grad` wraps both in a torch.autograd.Function so that
+SHAM2.forward composes with torch's optimizer, GradScaler and clip_grad_norm_ exactly as in the reference loop.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib, train_ops as T
+from ._lib import HcirError, check
+from .vit_engine import VitSpec
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _pad64(m: int) -> int:
+    return (m + 63) // 64 * 64
+
+
+class _Saved:
+    """Activations of one training forward (device buffers; rows padded to a multiple of 64 with zeros)."""
+    __slots__ = ("b", "t", "m", "x_in", "ln1", "qkv", "att", "lse", "x_mid", "ln2", "u", "h", "x_out", "patches")
+
+
+class VitTrainer:
+    """fp16 operand copies of a ViT's weights (as stored and transposed) + the training forward / backward."""
+
+    def __init__(self, spec: VitSpec, device: torch.device):
+        if device.type != "cuda":
+            raise HcirError(f"VitTrainer needs a HIP device, got {device} (no CPU fallback)")
+        if spec.dim % spec.heads or spec.dim // spec.heads != 64:
+            raise HcirError("hcir attention kernels support head_dim 64")
+        if any(l.ls1 is not None or l.ls2 is not None for l in spec.layers):
+            raise NotImplementedError("LayerScale is not on the training path")
+        self.L = _lib.lib()
+        self.device = device
+        self.spec = spec
+        self.dim, self.heads, self.eps, self.pos_mult = spec.dim, spec.heads, float(spec.eps), float(spec.pos_mult)
+        self.patch = int(spec.patch)
+        self.mlp = spec.layers[0].fc1_w.shape[0]
+        if self.dim % 256 or self.mlp % 256 or (3 * spec.conv_w.shape[2] * spec.conv_w.shape[3]) % 256:
+            raise HcirError("training path needs dim, mlp and C*P*P to be multiples of 256 (hcir_gemm_f16_tn)")
+        self._key = None
+        self.refresh()
+
+    # -- parameters in the order the autograd Function sees them ------------------------------------------------
+    def params(self) -> List[torch.Tensor]:
+        s = self.spec
+        out = [s.conv_w, s.conv_b, s.cls, s.pos]
+        for l in s.layers:
+            out += [l.ln1_w, l.ln1_b, l.qkv_w, l.qkv_b, l.proj_w, l.proj_b, l.ln2_w, l.ln2_b, l.fc1_w, l.fc1_b,
+                    l.fc2_w, l.fc2_b]
+        out += [s.final_ln_w, s.final_ln_b]
+        return out
+
+    def refresh(self) -> None:
+        """(Re)build the fp16 operand copies when a parameter changed (optimizer step, load_state_dict)."""
+        ps = self.params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key == self._key:
+            return
+        dev, s = self.device, self.spec
+        f16 = lambda t: t.detach().to(device=dev, dtype=torch.float16).contiguous()
+        f16t = lambda t: t.detach().to(device=dev, dtype=torch.float16).t().contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.conv_w = f16(s.conv_w.reshape(self.dim, -1))
+        self.conv_b, self.cls, self.pos = f32(s.conv_b), f32(s.cls.reshape(-1)), f32(s.pos.reshape(-1, self.dim))
+        self.lw = []
+        for l in s.layers:
+            if l.qkv_b is None:
+                raise NotImplementedError("qkv without bias is not on the training path")
+            self.lw.append(dict(
+                ln1_w=f32(l.ln1_w), ln1_b=f32(l.ln1_b), ln2_w=f32(l.ln2_w), ln2_b=f32(l.ln2_b),
+                qkv_w=f16(l.qkv_w), qkv_wt=f16t(l.qkv_w), qkv_b=f32(l.qkv_b),
+                proj_w=f16(l.proj_w), proj_wt=f16t(l.proj_w), proj_b=f32(l.proj_b),
+                fc1_w=f16(l.fc1_w), fc1_wt=f16t(l.fc1_w), fc1_b=f32(l.fc1_b),
+                fc2_w=f16(l.fc2_w), fc2_wt=f16t(l.fc2_w), fc2_b=f32(l.fc2_b)))
+        self.fln_w, self.fln_b = f32(s.final_ln_w), f32(s.final_ln_b)
+        self._key = key
+
+    # -- small helpers over the C ABI ---------------------------------------------------------------------------
+    def _gemm(self, a, k, w, bias, m, n, epi, out, st, what):
+        check(self.L.hcir_gemm_f16(a.data_ptr(), k, w.data_ptr(), k, _p(bias), None, m, n, k, epi, out.data_ptr(), n,
+                                   st), what)
+
+    def _ln(self, x, rows, d, ldx, g, b, y, st):
+        check(self.L.hcir_layernorm_f16(x.data_ptr(), _lib.F16, rows, d, ldx, g.data_ptr(), b.data_ptr(), self.eps,
+                                        y.data_ptr(), d, st), "hcir_layernorm_f16")
+
+    # -- forward ------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise HcirError(f"input is on {x.device}; the hcir ViT runs on a HIP device only")
+        self.refresh()
+        x = x.float().contiguous()
+        b, c, hh, ww = x.shape
+        ps, d, L, dev = self.patch, self.dim, self.L, self.device
+        if hh % ps or ww % ps:
+            raise HcirError("image sides must be multiples of the patch size")
+        t = (hh // ps) * (ww // ps) + 1
+        if t > 256:
+            raise HcirError("hcir_attn_bwd supports up to 256 tokens")
+        if t != self.pos.shape[0]:
+            raise HcirError(f"image gives {t} tokens but pos_embedding has {self.pos.shape[0]}")
+        m, mp = b * t, _pad64(b * t)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        z16 = lambda cols: torch.zeros((mp, cols), dtype=torch.float16, device=dev)
+        sv = _Saved()
+        sv.b, sv.t, sv.m = b, t, m
+        sv.x_in, sv.ln1, sv.qkv, sv.att, sv.lse, sv.x_mid, sv.ln2, sv.u, sv.h = ([] for _ in range(9))
+        # im2col of the patches in (c, ky, kx) order: the weight gradient of conv_proj needs it (data movement only)
+        gh, gw = hh // ps, ww // ps
+        pm = _pad64(b * gh * gw)
+        sv.patches = torch.zeros((pm, c * ps * ps), dtype=torch.float16, device=dev)
+        sv.patches[: b * gh * gw] = x.reshape(b, c, gh, ps, gw, ps).permute(0, 2, 4, 1, 3, 5).reshape(b * gh * gw, -1)
+        tok = z16(d)
+        kpad = self.conv_w.shape[1]
+        if kpad % 64:
+            raise HcirError("C*P*P must be a multiple of 64")
+        check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, ps, self.conv_w.data_ptr(), kpad, self.conv_b.data_ptr(),
+                                 self.cls.data_ptr(), self.pos.data_ptr(), self.pos_mult, d, tok.data_ptr(), _lib.F16,
+                                 st), "hcir_patch_embed")
+        scale = (d // self.heads) ** -0.5
+        cur = tok
+        for w in self.lw:
+            ln1, qkv, att = z16(d), z16(3 * d), z16(d)
+            lse = torch.empty((b, self.heads, t), dtype=torch.float32, device=dev)
+            self._ln(cur, m, d, d, w["ln1_w"], w["ln1_b"], ln1, st)
+            self._gemm(ln1, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
+            T.attn_fwd_lse(qkv, b, t, self.heads, scale, att, lse)
+            x_mid = cur.clone()
+            self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)")
+            ln2, u = z16(d), z16(self.mlp)
+            self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln2, st)
+            self._gemm(ln2, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
+            h = T.gelu_fwd(u)
+            x_out = x_mid.clone()
+            self._gemm(h, self.mlp, w["fc2_w"], w["fc2_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_out, st,
+                       "hcir_gemm_f16(fc2)")
+            for lst, v in ((sv.x_in, cur), (sv.ln1, ln1), (sv.qkv, qkv), (sv.att, att), (sv.lse, lse),
+                           (sv.x_mid, x_mid), (sv.ln2, ln2), (sv.u, u), (sv.h, h)):
+                lst.append(v)
+            cur = x_out
+        sv.x_out = cur
+        cls = torch.empty((b, d), dtype=torch.float32, device=dev)
+        check(L.hcir_cls_head(cur.data_ptr(), _lib.F16, b, t, d, self.fln_w.data_ptr(), self.fln_b.data_ptr(), self.eps,
+                              0, cls.data_ptr(), None, st), "hcir_cls_head")
+        return cls, sv
+
+    # -- backward -----------------------------------------------------------------------------------------------
+    def backward(self, sv: _Saved, d_cls: torch.Tensor) -> List[torch.Tensor]:
+        """Gradients (fp32, shapes of `params()`) of sum(cls * d_cls)."""
+        b, t, m, d, dev, L = sv.b, sv.t, sv.m, self.dim, self.device, self.L
+        mp = _pad64(m)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        f32z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        grads = {}
+        dres = f32z(mp, d)                                    # dL / d(residual stream), fp32
+        dy16 = torch.zeros((mp, d), dtype=torch.float16, device=dev)
+        g_flw, g_flb = f32z(d), f32z(d)
+        dcls16 = d_cls.detach().to(device=dev, dtype=torch.float16).contiguous()
+        T.layernorm_bwd(sv.x_out, dcls16, self.fln_w, self.eps, None, dres, g_flw, g_flb, accumulate=False, rows=b,
+                        ldx=t * d, ldr=t * d)
+        big16 = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)     # d_h / d_u
+        dqkv = torch.zeros((mp, 3 * d), dtype=torch.float16, device=dev)
+        datt = torch.zeros((mp, d), dtype=torch.float16, device=dev)
+        dln = torch.zeros((mp, d), dtype=torch.float16, device=dev)
+        layer_grads = []
+        scale = (d // self.heads) ** -0.5
+        nelem = m * d
+        for li in range(len(self.lw) - 1, -1, -1):
+            w = self.lw[li]
+            g = {k: f32z(*shape) for k, shape in (
+                ("ln1_w", (d,)), ("ln1_b", (d,)), ("qkv_w", (3 * d, d)), ("qkv_b", (3 * d,)), ("proj_w", (d, d)),
+                ("proj_b", (d,)), ("ln2_w", (d,)), ("ln2_b", (d,)), ("fc1_w", (self.mlp, d)), ("fc1_b", (self.mlp,)),
+                ("fc2_w", (d, self.mlp)), ("fc2_b", (d,)))}
+            # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+            check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
+            self._gemm(dy16, d, w["fc2_wt"], None, m, self.mlp, _lib.EPI_BIAS_F16, big16, st, "dgrad(fc2)")
+            T.gemm_tn(dy16, sv.h[li], g["fc2_w"], accumulate=False)
+            T.colsum(dy16, g["fc2_b"], accumulate=False, rows=m)
+            check(L.hcir_gelu_bwd_f16(sv.u[li].data_ptr(), big16.data_ptr(), m * self.mlp, big16.data_ptr(), st),
+                  "hcir_gelu_bwd_f16")
+            self._gemm(big16, self.mlp, w["fc1_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(fc1)")
+            T.gemm_tn(big16, sv.ln2[li], g["fc1_w"], accumulate=False)
+            T.colsum(big16, g["fc1_b"], accumulate=False, rows=m)
+            T.layernorm_bwd(sv.x_mid[li], dln, w["ln2_w"], self.eps, dres, dres, g["ln2_w"], g["ln2_b"],
+                            accumulate=False, rows=m)
+            # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
+            check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
+            self._gemm(dy16, d, w["proj_wt"], None, m, d, _lib.EPI_BIAS_F16, datt, st, "dgrad(proj)")
+            T.gemm_tn(dy16, sv.att[li], g["proj_w"], accumulate=False)
+            T.colsum(dy16, g["proj_b"], accumulate=False, rows=m)
+            T.attn_bwd(sv.qkv[li], sv.att[li], datt, sv.lse[li], b, t, self.heads, scale, dqkv)
+            self._gemm(dqkv, 3 * d, w["qkv_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(qkv)")
+            T.gemm_tn(dqkv, sv.ln1[li], g["qkv_w"], accumulate=False)
+            T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
+            T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
+                            accumulate=False, rows=m)
+            layer_grads.append(g)
+        layer_grads.reverse()
+        # ---- patch embedding: tok[b][0] = cls + pos_mult pos[0]; tok[b][1+p] = W patch + bias + pos_mult pos[1+p]
+        dtok = dres[:m].view(b, t, d)
+        g_cls = dtok[:, 0].sum(0)
+        g_pos = dtok.sum(0) * self.pos_mult
+        npat = b * (t - 1)
+        dpatch = torch.zeros((_pad64(npat), d), dtype=torch.float16, device=dev)
+        dpatch[:npat] = dtok[:, 1:].reshape(npat, d)
+        g_cw = f32z(d, sv.patches.shape[1])
+        g_cb = f32z(d)
+        T.gemm_tn(dpatch, sv.patches, g_cw, accumulate=False)
+        T.colsum(dpatch, g_cb, accumulate=False, rows=npat)
+        s = self.spec
+        out = [g_cw.view(s.conv_w.shape), g_cb, g_cls.view(s.cls.shape), g_pos.view(s.pos.shape)]
+        for g in layer_grads:
+            out += [g["ln1_w"], g["ln1_b"], g["qkv_w"], g["qkv_b"], g["proj_w"], g["proj_b"], g["ln2_w"], g["ln2_b"],
+                    g["fc1_w"], g["fc1_b"], g["fc2_w"], g["fc2_b"]]
+        out += [g_flw, g_flb]
+        return out
+
+
+class _VitClsFn(torch.autograd.Function):
+    """cls = LN_final(ViT(x))[:, 0] with gradients for every backbone parameter (none for the images)."""
+
+    @staticmethod
+    def forward(ctx, trainer: VitTrainer, x: torch.Tensor, *params):
+        cls, saved = trainer.forward(x)
+        ctx.trainer, ctx.saved = trainer, saved
+        ctx.mask = [p.requires_grad for p in params]
+        return cls
+
+    @staticmethod
+    def backward(ctx, d_cls):
+        grads = ctx.trainer.backward(ctx.saved, d_cls)
+        ctx.saved = None
+        return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.mask))
+
+
+def vit_cls_with_grad(trainer: VitTrainer, x: torch.Tensor) -> torch.Tensor:
+    return _VitClsFn.apply(trainer, x, *trainer.params())

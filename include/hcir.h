@@ -299,6 +299,76 @@ int hcir_retrieval_metrics(const int64_t* retrieved, int64_t nq, int32_t kmax, c
                            const int32_t* ks, int32_t nk, int32_t* hit, double* ap, double* recall_mean,
                            double* map_mean, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * Training side of the HSimCLR step (HP/src/pretrain_engine.py:681-751):
+ * the backward of the ViT blocks and the two small losses.  Gradients flow as fp32 along the residual stream
+ * and as fp16 GEMM operands; any loss scale (torch GradScaler, :745) passes through linearly.
+ * ------------------------------------------------------------------ */
+
+/* nn.GELU() forward / backward on fp16 buffers (n % 8 == 0): h = gelu(u);  du = dh * gelu'(u)
+ * (MLPBlock / timm Mlp activation, HP/src/main_backbone.py:554; HP/src/models_vit.py:19). */
+int hcir_gelu_fwd_f16(const void* u, int64_t n, void* h, void* stream);
+int hcir_gelu_bwd_f16(const void* u, const void* dh, int64_t n, void* du, void* stream);
+
+/* y_f16 = fp16(a + b)  (b may be NULL): the fp32 residual gradient as the next GEMM's fp16 operand. n % 4 == 0 */
+int hcir_add_f32_f16(const float* a, const float* b, int64_t n, void* y, void* stream);
+
+/* nn.LayerNorm(d, eps) backward over `rows` rows (ln_1 / ln_2 / encoder.ln; models_vit norm1 / norm2):
+ *   xhat = (x - mean) rstd,  g = dy o gamma,  dx = rstd (g - mean(g) - xhat mean(g o xhat))
+ *   dres_out[row] = (dres_in ? dres_in[row] : 0) + dx            fp32, row pitch ldr (dres_out may alias dres_in)
+ *   dgamma (+)= sum_rows dy o xhat,  dbeta (+)= sum_rows dy       (accumulate != 0: added to the existing values)
+ * x is the layer's INPUT (residual stream, HCIR_F32 or HCIR_F16; statistics are recomputed), dy fp16.
+ * workspace: 2 * hcir_layernorm_bwd_blocks(rows) * d floats (two-stage, fixed-order column sums). */
+int32_t hcir_layernorm_bwd_blocks(int64_t rows);
+int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx, const void* dy_f16,
+                       int64_t lddy, const float* gamma, float eps, const float* dres_in, float* dres_out,
+                       int64_t ldr, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* out[n] (+)= sum_m x[m][n] of an fp16 matrix: the bias gradient of a Linear layer.
+ * workspace: hcir_colsum_chunks(m) * n floats. */
+int32_t hcir_colsum_chunks(int64_t m);
+int hcir_colsum_f16(const void* x, int64_t m, int32_t n, int64_t ldx, float* out, int accumulate, float* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Weight gradient of a Linear layer:  dw[N][K] (+)= A[M][N]^T . B[M][K]   (A = dY, B = the layer's input), fp16
+ * operands, fp32 accumulate, fp32 output.  Both operands are read as stored (row-major, M the slow index): tiles go
+ * to LDS by LDS-DMA and the MFMA fragments are read TRANSPOSED (ds_read_b64_tr_b16).  M is split over workgroups;
+ * the partial tiles meet in `workspace` (hcir_gemm_f16_tn_workspace_bytes) and are summed in split order
+ * (deterministic, no atomics).  Requirements: N % 256 == 0 or N % 128 == 0, K % 128 == 0, lda/ldb % 8 == 0. */
+size_t hcir_gemm_f16_tn_workspace_bytes(int64_t m, int32_t n, int32_t k);
+int hcir_gemm_f16_tn(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t m, int32_t n, int32_t k,
+                     float* dw, int64_t lddw, int accumulate, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Training forward of the attention: hcir_attn_fwd for all T query rows that also writes, per (b, head, query),
+ * lse[b][h][q] = log2 sum_k exp2((s_qk - max) scale log2e) + max scale log2e  (log2 domain), from which the
+ * backward recomputes P = exp2(s scale log2e - lse). */
+int hcir_attn_fwd_lse(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale, void* out,
+                      float* lse, void* stream);
+
+/* Backward of hcir_attn_fwd over packed qkv [B][T][3][H][64] (fp16): given the forward output `out` [B][T][H*64],
+ * its gradient d_out (fp16) and lse, writes d_qkv [B][T][3][H][64] (fp16):
+ *   P = softmax(scale q k^T);  dV = P^T dO;  dP = dO V^T;  dS = P o (dP - rowsum(dO o O));
+ *   dQ = scale dS K;  dK = scale dS^T Q.
+ * Requirements: hd == 64, T <= 256.  (HP/src/models_vit.py:69-78; nn.MultiheadAttention.) */
+int hcir_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, int64_t b, int32_t t,
+                  int32_t h, int32_t hd, float scale, void* d_qkv, void* stream);
+
+/* nn.TripletMarginLoss(margin, p=2, eps, reduction='mean') (HP/src/pretrain_engine.py:96-97,717-721), fp32 [B][D]:
+ *   d(x, y) = || x - y + eps ||_2,  loss = mean_i max(d(a_i, p_i) - d(a_i, n_i) + margin, 0).
+ * row_loss [B] and dist [2][B] are kept for the backward; grad_out is a DEVICE scalar. */
+int hcir_triplet_margin_fwd(const float* anchor, const float* positive, const float* negative, int64_t b, int32_t d,
+                            float margin, float eps, float* loss, float* row_loss, float* dist, void* stream);
+int hcir_triplet_margin_bwd(const float* anchor, const float* positive, const float* negative, int64_t b, int32_t d,
+                            float eps, const float* row_loss, const float* dist, const float* grad_out,
+                            float* d_anchor, float* d_positive, float* d_negative, void* stream);
+
+/* F.mse_loss(x, y, reduction='mean') (HP/src/pretrain_engine.py:730) and its backward; workspace: 256 floats. */
+int hcir_mse_fwd(const float* x, const float* y, int64_t n, float* loss, float* workspace, void* stream);
+int hcir_mse_bwd(const float* x, const float* y, int64_t n, const float* grad_out, float* dx, float* dy,
+                 void* stream);
+
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 

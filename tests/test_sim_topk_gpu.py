@@ -234,3 +234,53 @@ def test_sim_topk_f32_top50_bit_exact(ops, nq, ng, d, k):
     rv, ri = oknn.cosine_topk(q, g, k)
     np.testing.assert_array_equal(idx.cpu().numpy(), ri)
     np.testing.assert_array_equal(val.cpu().numpy(), rv)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("nq,k", [(64, 10), (64, 50), (20, 16), (128, 33)])
+def test_sim_topk_candidate_overflow_falls_back(ops, dtype, nq, k):
+    """<= 128 queries run the candidate-append flow (lists only in the prefix, every later row at / above the
+    floor appended to a per-query buffer).  A gallery ordered so that the later rows systematically beat the
+    first ones (a class-ordered gallery and queries of a late class) overflows the buffers: the device flag must
+    route the call through the list-keeping flow, same exact result."""
+    rng = np.random.default_rng(51)
+    ng, d = 60000, 128
+    base = rng.standard_normal(d).astype(np.float32)
+    q = (base[None] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    g = rng.standard_normal((ng, d)).astype(np.float32)
+    g[16384:] = base[None] + 0.3 * rng.standard_normal((ng - 16384, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    qd, gd = torch.from_numpy(q).cuda().to(dtype), torch.from_numpy(g).cuda().to(dtype)
+    val, idx = ops.sim_topk(qd, gd, k, idx_base=9)
+    val, idx = val.cpu().numpy(), idx.cpu().numpy() - 9
+    assert (idx >= 16384).all()
+    if dtype == torch.float32:
+        rv, ri = oknn.cosine_topk(q, g, k)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(val, rv)
+    else:
+        rv, ri = oknn.stable_topk_np(_scores64_rounded(qd, gd), k + 1)
+        np.testing.assert_allclose(val, rv[:, :k], atol=1e-5, rtol=0)
+        gap = rv[:, :-1] - rv[:, 1:]
+        safe = np.minimum(np.concatenate([np.full((nq, 1), np.inf), gap[:, :-1]], 1), gap) > 1e-5
+        np.testing.assert_array_equal(idx[safe], ri[:, :k][safe])
+
+
+@pytest.mark.parametrize("k", [10, 16, 17, 50, 64])
+def test_sim_topk_candidate_flow_ties_across_prefix(ops, k):
+    """Exact duplicates of the best rows on both sides of the prefix boundary and inside the prefix: the
+    candidate flow's `> floor` (k <= 16) / `>= floor` (group floors, k > 16) rules must keep the tie-break
+    (smaller index first) bit-exactly, fp32."""
+    rng = np.random.default_rng(52)
+    nq, ng, d = 40, 70000, 64
+    q, g = rng.standard_normal((nq, d), dtype=np.float32), rng.standard_normal((ng, d), dtype=np.float32)
+    for i in range(nq):                       # every query's best row is repeated k + 3 times over the gallery
+        best = g[100 + i].copy()
+        q[i] = best
+        pos = rng.choice(np.arange(200, ng), size=k + 2, replace=False)
+        g[pos] = best
+    val, idx = ops.sim_topk(torch.from_numpy(q).cuda(), torch.from_numpy(g).cuda(), k)
+    rv, ri = oknn.cosine_topk(q, g, k)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    np.testing.assert_array_equal(val.cpu().numpy(), rv)

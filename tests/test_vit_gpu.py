@@ -384,8 +384,12 @@ def test_vit_requires_no_grad_and_device(L):
     with torch.no_grad(), pytest.raises(HcirError):
         model.extract_features(x)  # CPU tensor: no fallback
     model = model.cuda()
+    f = model.extract_features(x.cuda())  # autograd on: the differentiable forward (hcir.vit_train)
+    assert f.requires_grad and f.shape == (1, 768)
+    with torch.no_grad():
+        assert _cos_err(f.detach().cpu(), model.extract_features(x.cuda()).cpu()) <= 1e-5   # same embedding
     with pytest.raises(NotImplementedError):
-        model.extract_features(x.cuda())  # autograd on: backward is not built
+        model.backbone(x.cuda())  # class token + pooled patches: inference-only
     with pytest.raises(ValueError):
         SHAM2("vgg16")
 

@@ -13,10 +13,10 @@
 //                                      ds_read_b64_tr_b16, in the permuted k order of an accumulator operand
 //                                      (cdna_hip_programming.md §3);
 //   dQ^T = K^T . dS^T                  contracts over the key = the lane index: dS crosses LDS once ([q][key] image,
-//                                      private to the wave), the per-wave partial dQ tiles (its 64 keys) meet in a
-//                                      padded fp32 LDS tile (ds_add_f32) and leave as whole fp16 rows.
+//                                      private to the wave), the per-wave partial dQ tiles (its 64 keys) meet in
+//                                      padded fp32 LDS slabs, summed in wave order, and leave as whole fp16 rows.
 // P is recomputed from the forward's per-row log2-sum-exp (hcir_attn_fwd_lse); D from dO and O at kernel start.
-// LDS: Q, dO, K images (3 x 32 KB), dS staging 4 x 4 KB, dQ tile 8.3 KB, row constants 2 KB: 1 workgroup per CU,
+// LDS: Q, dO, K images (3 x 32 KB), dS staging 4 x 4 KB, dQ slabs 4 x 8.3 KB, row constants 2 KB: 1 workgroup per CU,
 // one wave per SIMD (the kernel uses ~350 registers).  Correctness-first layouts: the images carry the row-read
 // swizzle only; transposed reads see some bank conflicts (the kernel is ~2 % of a training step).
 #include "common.h"
@@ -42,13 +42,13 @@ __device__ __forceinline__ int img_off(int row, int c16) { return row * 128 + ((
 __device__ __forceinline__ int img_off_e(int row, int e0) { return img_off(row, e0 >> 3) + (e0 & 7) * 2; }
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) char lds[3 * kTP * 128 + 4 * 4096 + 32 * 65 * 4 + 2 * kTP * 4];
+  __shared__ __attribute__((aligned(16))) char lds[3 * kTP * 128 + 4 * 4096 + 4 * 32 * 65 * 4 + 2 * kTP * 4];
   char* qs = lds;
   char* dos = lds + kTP * 128;
   char* ks = lds + 2 * kTP * 128;
   char* dss = lds + 3 * kTP * 128;                                  // [4 waves][32 q][128 B]
-  float* dqt = reinterpret_cast<float*>(lds + 3 * kTP * 128 + 4 * 4096);  // [32][65]
-  float* dsum = dqt + 32 * 65;                                      // D[q]
+  float* dqt = reinterpret_cast<float*>(lds + 3 * kTP * 128 + 4 * 4096);  // [4 waves][32][65]
+  float* dsum = dqt + 4 * 32 * 65;                                  // D[q]
   float* lrow = dsum + kTP;                                         // lse[q]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,8 +95,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
     dsum[q] = dsv;
     lrow[q] = lv;
   }
-  for (int i = tid; i < 32 * 65; i += 256) dqt[i] = 0.f;
-
   // ---- this wave's K and V fragments (B operands: lane (key = 64 w + 32 kt + r, half h) holds [key][16 s + 8 h ..])
   f16x8 kf[2][4], vf[2][4];
 #pragma unroll
@@ -218,20 +216,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
         dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf, dsb, dqa[dt], 0, 0, 0);
       }
     }
-    // the four waves' partial tiles meet in LDS (row pitch 65 floats: the 32 queries of a register spread over
-    // the banks), then leave as whole fp16 rows
+    // the four waves' partial tiles (their 64 keys each) go to per-wave LDS slabs (row pitch 65 floats: the 32
+    // queries of a register spread over the banks) and are summed in wave order: deterministic, no LDS atomics
+    // (an atomic version changed low bits from run to run, which fp16 roundings downstream amplified to 1e-4)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) atomicAdd(&dqt[r * 65 + 32 * dt + acc_row(i, h)], dqa[dt][i]);
+      for (int i = 0; i < 16; ++i) dqt[wave * (32 * 65) + r * 65 + 32 * dt + acc_row(i, h)] = dqa[dt][i];
     __syncthreads();
     {
       const int q = tid >> 3, c = tid & 7;
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o[e] = (_Float16)(dqt[q * 65 + c * 8 + e] * a.scale);
-        dqt[q * 65 + c * 8 + e] = 0.f;
+        float sacc = dqt[q * 65 + c * 8 + e];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sacc += dqt[w * (32 * 65) + q * 65 + c * 8 + e];
+        o[e] = (_Float16)(sacc * a.scale);
       }
       if (q0 + q < a.t) *reinterpret_cast<f16x8*>(dqg + (q0 + q) * qkv_stride + c * 8) = o;
     }

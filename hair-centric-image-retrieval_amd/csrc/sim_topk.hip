@@ -891,9 +891,14 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
 // --------------------------------------------------------------------------
 // select: top-k of an UNSORTED candidate buffer (what the candidate-append scans leave: [cap][nq], cnt[nq]) plus an
 // optional sorted list per query (the prefix result).  One wave per query, every entry a 64-bit (score, ~row) key
-// in a register (lane l owns candidates l, l + 64, ...; its last slot takes entry l of the sorted list); k rounds
-// of wave maximum, the winner's slot cleared by key equality (row indices are unique).  No list heads to
-// advance, no loads or stores inside the loop.  cap = 64 (LPL - 1).
+// in a register (lane l owns candidates l, l + 64, ...; its last slot takes entry l of the sorted list).
+//   1. the k-th largest SCORE by a bitwise search (32 steps of "how many scores are >= t": one compare-and-count
+//      per slot and a wave sum) - no key ever moves;
+//   2. ties at that score (rare) are cut by the same search on the row half of the key: exactly k keys selected;
+//   3. the selected keys are compacted to one per lane through LDS (ballot / mbcnt positions) and ranked by
+//      counting, lane i comparing with every other lane's key (64 readlane steps); lane i stores at its rank.
+// (k rounds of wave maximum over all slots - the first version - cost 14.6 us at 15 slots and 72-78 us at 47.)
+// cap = 64 (LPL - 1).
 // --------------------------------------------------------------------------
 struct SelectArgs {
   const float* cand_val;
@@ -911,10 +916,17 @@ struct SelectArgs {
   int gate_want;
 };
 
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 template <int LPL>
 __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ uint64_t compact[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
   if (qi >= a.nq) return;
   if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
   int cnt = a.cand_cnt[qi];
@@ -928,20 +940,70 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
   }
   kq[LPL - 1] = 0ull;
   if (a.pre_val && lane < a.kpre) kq[LPL - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
-  uint64_t mine = 0ull;
-  for (int o = 0; o < a.k; ++o) {
-    uint64_t best = kq[0];
+  // total live keys (merge_key never returns 0 for a live entry: the score half has its top bit set or is ~u)
+  int live = 0;
 #pragma unroll
-    for (int j = 1; j < LPL; ++j) best = kq[j] > best ? kq[j] : best;
-    const uint64_t wm = wave_max_u64(best);
-    mine = (lane == o) ? wm : mine;
+  for (int j = 0; j < LPL; ++j) live += kq[j] != 0ull ? 1 : 0;
+  live = wave_sum_i32(live);
+  const int k = a.k < live ? a.k : live;   // fewer live keys than k: the rest of the output is empty slots
+
+  // 1. T = k-th largest score half
+  uint32_t T = 0u;
+  if (k > 0) {
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t t = T | (1u << bit);
+      int c = 0;
 #pragma unroll
-    for (int j = 0; j < LPL; ++j) kq[j] = (kq[j] == wm) ? 0ull : kq[j];
+      for (int j = 0; j < LPL; ++j) c += (uint32_t)(kq[j] >> 32) >= t ? 1 : 0;
+      if (wave_sum_i32(c) >= k) T = t;
+    }
   }
-  if (lane < a.k) {
-    const bool none = mine == 0ull;
-    a.out_val[qi * a.k + lane] = none ? kNegInf : merge_key_val(mine);
-    a.out_idx[qi * a.k + lane] = none ? -1 : (int64_t)merge_key_idx(mine) + a.idx_base;
+  // 2. keys above T are in; `need` of the keys AT T are in, largest row half (= smallest row) first
+  int cgt = 0, ceq = 0;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    const uint32_t u = (uint32_t)(kq[j] >> 32);
+    cgt += u > T ? 1 : 0;
+    ceq += (u == T && kq[j] != 0ull) ? 1 : 0;
+  }
+  cgt = wave_sum_i32(cgt);
+  ceq = wave_sum_i32(ceq);
+  const int need = k - cgt;
+  uint32_t Lo = 0u;  // smallest accepted row half among the ties
+  if (need < ceq) {
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t t = Lo | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) c += ((uint32_t)(kq[j] >> 32) == T && (uint32_t)kq[j] >= t && kq[j] != 0ull) ? 1 : 0;
+      if (wave_sum_i32(c) >= need) Lo = t;
+    }
+  }
+  // 3. compaction: position = keys selected in earlier slots + selected lanes below this one in this slot
+  int base = 0;
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    const uint32_t u = (uint32_t)(kq[j] >> 32);
+    const bool sel = k > 0 && kq[j] != 0ull && (u > T || (u == T && (uint32_t)kq[j] >= Lo));
+    const uint64_t m = __ballot(sel);
+    if (sel) compact[wave][base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = kq[j];
+    base += __builtin_popcountll(m);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave wrote and reads: LDS is in order, this pins the compiler
+  const uint64_t mine = lane < k ? compact[wave][lane] : 0ull;
+  int rank = 0;
+#pragma unroll 8
+  for (int j = 0; j < 64; ++j) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
+    rank += ((((uint64_t)hi << 32) | lo) > mine) ? 1 : 0;
+  }
+  if (lane < k) {
+    a.out_val[qi * a.k + rank] = merge_key_val(mine);
+    a.out_idx[qi * a.k + rank] = (int64_t)merge_key_idx(mine) + a.idx_base;
+  } else if (lane < a.k) {   // fewer than k rows in all
+    a.out_val[qi * a.k + lane] = kNegInf;
+    a.out_idx[qi * a.k + lane] = -1;
   }
 }
 

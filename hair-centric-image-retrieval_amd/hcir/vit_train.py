@@ -5,8 +5,11 @@ HP/src/pretrain_engine.py:682-745).
 `VitTrainer.forward(x)` runs
     patch_embed -> depth x [ LN1 -> qkv GEMM -> attention (+ log-sum-exp) -> proj GEMM + residual ->
                              LN2 -> fc1 GEMM -> GELU -> fc2 GEMM + residual ] -> final LN of the class token
-keeping, per block, what the backward needs (fp16: block input, both LayerNorm outputs, qkv, attention output,
-fc1 pre-activation and activation; fp32: the attention's row log-sum-exp).  `VitTrainer.backward(saved, d_cls)`
+keeping, per block, what the backward needs (fp16: block input, qkv, attention output, the residual after the
+attention and the fc1 pre-activation; fp32: the attention's row log-sum-exp: 3.0 MB per image and block at
+T = 197).  Both LayerNorm outputs and the GELU output are RECOMPUTED in the backward (three HBM-bound launches per
+block) instead of stored: 1.8 MB per image and block less, which is what lets config C3's batch of 1024 - three
+differentiable forwards per step - fit in HBM (112 GB of saved activations).  `VitTrainer.backward(saved, d_cls)`
 walks the blocks in reverse:
     dgrad    dX = dY . W          hcir_gemm_f16 against a transposed fp16 copy of the weight
     wgrad    dW = dY^T . X        hcir_gemm_f16_tn (operands as stored, transposed LDS reads, split-M, deterministic)
@@ -38,7 +41,7 @@ def _pad64(m: int) -> int:
 
 class _Saved:
     """Activations of one training forward (device buffers; rows padded to a multiple of 64 with zeros)."""
-    __slots__ = ("b", "t", "m", "x_in", "ln1", "qkv", "att", "lse", "x_mid", "ln2", "u", "h", "x_out", "patches")
+    __slots__ = ("b", "t", "m", "x_in", "qkv", "att", "lse", "x_mid", "u", "x_out", "patches")
 
 
 class VitTrainer:
@@ -123,10 +126,16 @@ class VitTrainer:
             raise HcirError(f"image gives {t} tokens but pos_embedding has {self.pos.shape[0]}")
         m, mp = b * t, _pad64(b * t)
         st = torch.cuda.current_stream(dev).cuda_stream
-        z16 = lambda cols: torch.zeros((mp, cols), dtype=torch.float16, device=dev)
+        def z16(cols):
+            """[mp, cols] fp16 whose pad rows (>= m) are zero: kernels only ever write rows < m."""
+            buf = torch.empty((mp, cols), dtype=torch.float16, device=dev)
+            if mp > m:
+                buf[m:].zero_()
+            return buf
+
         sv = _Saved()
         sv.b, sv.t, sv.m = b, t, m
-        sv.x_in, sv.ln1, sv.qkv, sv.att, sv.lse, sv.x_mid, sv.ln2, sv.u, sv.h = ([] for _ in range(9))
+        sv.x_in, sv.qkv, sv.att, sv.lse, sv.x_mid, sv.u = ([] for _ in range(6))
         # im2col of the patches in (c, ky, kx) order: the weight gradient of conv_proj needs it (data movement only)
         gh, gw = hh // ps, ww // ps
         pm = _pad64(b * gh * gw)
@@ -141,23 +150,23 @@ class VitTrainer:
                                  st), "hcir_patch_embed")
         scale = (d // self.heads) ** -0.5
         cur = tok
+        ln, h = z16(d), z16(self.mlp)          # not kept: recomputed in the backward
         for w in self.lw:
-            ln1, qkv, att = z16(d), z16(3 * d), z16(d)
+            qkv, att = z16(3 * d), z16(d)
             lse = torch.empty((b, self.heads, t), dtype=torch.float32, device=dev)
-            self._ln(cur, m, d, d, w["ln1_w"], w["ln1_b"], ln1, st)
-            self._gemm(ln1, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
+            self._ln(cur, m, d, d, w["ln1_w"], w["ln1_b"], ln, st)
+            self._gemm(ln, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
             T.attn_fwd_lse(qkv, b, t, self.heads, scale, att, lse)
             x_mid = cur.clone()
             self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)")
-            ln2, u = z16(d), z16(self.mlp)
-            self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln2, st)
-            self._gemm(ln2, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
-            h = T.gelu_fwd(u)
+            u = z16(self.mlp)
+            self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln, st)
+            self._gemm(ln, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
+            check(L.hcir_gelu_fwd_f16(u.data_ptr(), m * self.mlp, h.data_ptr(), st), "hcir_gelu_fwd_f16")
             x_out = x_mid.clone()
             self._gemm(h, self.mlp, w["fc2_w"], w["fc2_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_out, st,
                        "hcir_gemm_f16(fc2)")
-            for lst, v in ((sv.x_in, cur), (sv.ln1, ln1), (sv.qkv, qkv), (sv.att, att), (sv.lse, lse),
-                           (sv.x_mid, x_mid), (sv.ln2, ln2), (sv.u, u), (sv.h, h)):
+            for lst, v in ((sv.x_in, cur), (sv.qkv, qkv), (sv.att, att), (sv.lse, lse), (sv.x_mid, x_mid), (sv.u, u)):
                 lst.append(v)
             cur = x_out
         sv.x_out = cur
@@ -181,6 +190,8 @@ class VitTrainer:
         T.layernorm_bwd(sv.x_out, dcls16, self.fln_w, self.eps, None, dres, g_flw, g_flb, accumulate=False, rows=b,
                         ldx=t * d, ldr=t * d)
         big16 = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)     # d_h / d_u
+        hbuf = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)      # gelu(u), recomputed per block
+        lnbuf = torch.zeros((mp, d), dtype=torch.float16, device=dev)            # LayerNorm output, recomputed
         dqkv = torch.zeros((mp, 3 * d), dtype=torch.float16, device=dev)
         datt = torch.zeros((mp, d), dtype=torch.float16, device=dev)
         dln = torch.zeros((mp, d), dtype=torch.float16, device=dev)
@@ -196,12 +207,14 @@ class VitTrainer:
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
             self._gemm(dy16, d, w["fc2_wt"], None, m, self.mlp, _lib.EPI_BIAS_F16, big16, st, "dgrad(fc2)")
-            T.gemm_tn(dy16, sv.h[li], g["fc2_w"], accumulate=False)
+            check(L.hcir_gelu_fwd_f16(sv.u[li].data_ptr(), m * self.mlp, hbuf.data_ptr(), st), "hcir_gelu_fwd_f16")
+            T.gemm_tn(dy16, hbuf, g["fc2_w"], accumulate=False)
             T.colsum(dy16, g["fc2_b"], accumulate=False, rows=m)
             check(L.hcir_gelu_bwd_f16(sv.u[li].data_ptr(), big16.data_ptr(), m * self.mlp, big16.data_ptr(), st),
                   "hcir_gelu_bwd_f16")
             self._gemm(big16, self.mlp, w["fc1_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(fc1)")
-            T.gemm_tn(big16, sv.ln2[li], g["fc1_w"], accumulate=False)
+            self._ln(sv.x_mid[li], m, d, d, w["ln2_w"], w["ln2_b"], lnbuf, st)
+            T.gemm_tn(big16, lnbuf, g["fc1_w"], accumulate=False)
             T.colsum(big16, g["fc1_b"], accumulate=False, rows=m)
             T.layernorm_bwd(sv.x_mid[li], dln, w["ln2_w"], self.eps, dres, dres, g["ln2_w"], g["ln2_b"],
                             accumulate=False, rows=m)
@@ -212,7 +225,8 @@ class VitTrainer:
             T.colsum(dy16, g["proj_b"], accumulate=False, rows=m)
             T.attn_bwd(sv.qkv[li], sv.att[li], datt, sv.lse[li], b, t, self.heads, scale, dqkv)
             self._gemm(dqkv, 3 * d, w["qkv_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(qkv)")
-            T.gemm_tn(dqkv, sv.ln1[li], g["qkv_w"], accumulate=False)
+            self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
+            T.gemm_tn(dqkv, lnbuf, g["qkv_w"], accumulate=False)
             T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
             T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
                             accumulate=False, rows=m)

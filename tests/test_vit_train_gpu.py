@@ -80,7 +80,7 @@ def test_vit_backward_vs_oracle_autograd():
     # second backward through a fresh forward accumulates into .grad like torch
     g0 = named["encoder.layers.encoder_layer_5.mlp.0.weight"].grad.clone()
     (model.backbone.forward_cls(x.cuda()) * wgt.cuda()).sum().backward()
-    assert _rel(named["encoder.layers.encoder_layer_5.mlp.0.weight"].grad, 2 * g0) <= 1e-5
+    assert _rel(named["encoder.layers.encoder_layer_5.mlp.0.weight"].grad, 2 * g0) <= 1e-6   # and deterministic
 
 
 def test_vit_backward_gradient_direction_decreases_loss():

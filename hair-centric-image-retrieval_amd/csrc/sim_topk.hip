@@ -916,40 +916,32 @@ struct SelectArgs {
   int gate_want;
 };
 
+// wave-uniform sum of an int over the 64 lanes: four DPP steps inside each row of 16 lanes, then four v_readlane.
+// (A __shfl_xor butterfly is six dependent ds_bpermute round trips: the 32-step searches below spent 11 us in them.)
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: every lane holds its row's sum
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
 }
 
+// The k largest of the wave's keys kq[LPL] (0 = empty slot), one per lane (unsorted) plus its rank among them:
+// steps 1-3 of the select comment above.  `compact` is the wave's 64-entry LDS scratch.  Returns the number of keys
+// found (min(k, live keys)); lanes >= that hold key 0.
 template <int LPL>
-__global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
-  __shared__ uint64_t compact[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
-  if (qi >= a.nq) return;
-  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
-  int cnt = a.cand_cnt[qi];
-  cnt = cnt < a.cap ? cnt : a.cap;
-  uint64_t kq[LPL];
-#pragma unroll
-  for (int j = 0; j < LPL - 1; ++j) {
-    const int e = lane + 64 * j;
-    kq[j] = 0ull;
-    if (e < cnt) kq[j] = merge_key(a.cand_val[(int64_t)e * a.nq + qi], a.cand_idx[(int64_t)e * a.nq + qi]);
-  }
-  kq[LPL - 1] = 0ull;
-  if (a.pre_val && lane < a.kpre) kq[LPL - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
-  // total live keys (merge_key never returns 0 for a live entry: the score half has its top bit set or is ~u)
+__device__ __forceinline__ int select_keys(const uint64_t (&kq)[LPL], int kwant, int lane, uint64_t* compact,
+                                           uint64_t& mine, int& rank) {
   int live = 0;
 #pragma unroll
   for (int j = 0; j < LPL; ++j) live += kq[j] != 0ull ? 1 : 0;
   live = wave_sum_i32(live);
-  const int k = a.k < live ? a.k : live;   // fewer live keys than k: the rest of the output is empty slots
-
+  const int k = kwant < live ? kwant : live;
   // 1. T = k-th largest score half
   uint32_t T = 0u;
   if (k > 0) {
+#pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t t = T | (1u << bit);
       int c = 0;
@@ -971,6 +963,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
   const int need = k - cgt;
   uint32_t Lo = 0u;  // smallest accepted row half among the ties
   if (need < ceq) {
+#pragma unroll 1
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t t = Lo | (1u << bit);
       int c = 0;
@@ -986,24 +979,126 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
     const uint32_t u = (uint32_t)(kq[j] >> 32);
     const bool sel = k > 0 && kq[j] != 0ull && (u > T || (u == T && (uint32_t)kq[j] >= Lo));
     const uint64_t m = __ballot(sel);
-    if (sel) compact[wave][base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = kq[j];
+    if (sel) compact[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = kq[j];
     base += __builtin_popcountll(m);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave wrote and reads: LDS is in order, this pins the compiler
-  const uint64_t mine = lane < k ? compact[wave][lane] : 0ull;
-  int rank = 0;
+  mine = lane < k ? compact[lane] : 0ull;
+  rank = 0;
 #pragma unroll 8
   for (int j = 0; j < 64; ++j) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
     rank += ((((uint64_t)hi << 32) | lo) > mine) ? 1 : 0;
   }
+  return k;
+}
+
+template <int LPL>
+__global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
+  __shared__ uint64_t compact[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+  if (qi >= a.nq) return;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  int cnt = a.cand_cnt[qi];
+  cnt = cnt < a.cap ? cnt : a.cap;
+  uint64_t kq[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL - 1; ++j) {
+    const int e = lane + 64 * j;
+    kq[j] = 0ull;
+    if (e < cnt) kq[j] = merge_key(a.cand_val[(int64_t)e * a.nq + qi], a.cand_idx[(int64_t)e * a.nq + qi]);
+  }
+  kq[LPL - 1] = 0ull;
+  if (a.pre_val && lane < a.kpre) kq[LPL - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
+  uint64_t mine;
+  int rank;
+  const int k = select_keys<LPL>(kq, a.k, lane, compact[wave], mine, rank);
   if (lane < k) {
     a.out_val[qi * a.k + rank] = merge_key_val(mine);
     a.out_idx[qi * a.k + rank] = (int64_t)merge_key_idx(mine) + a.idx_base;
   } else if (lane < a.k) {   // fewer than k rows in all
     a.out_val[qi * a.k + lane] = kNegInf;
     a.out_idx[qi * a.k + lane] = -1;
+  }
+}
+
+// --------------------------------------------------------------------------
+// merge of SORTED partial lists (the prefix lists: nlists x [nq][16]) by selection instead of k rounds of wave
+// maximum: (a) the kout lists with the largest HEAD keys are found with select_keys on the heads (one slot per
+// list); an entry of any other list is below its own head, hence below kout entries of those lists, and cannot be
+// in the top kout: (b) only those kout x 16 <= 256 entries are loaded (4 slots per lane) and (c) selected and ranked.
+// Exact under the (score desc, row asc) order (keys are unique).  ~8 us where the rounds took 17-19 us.
+// Same groups / outputs as topk_merge32_kernel (out_idx32, kth_val, zero_cnt); kin == 16, kout <= 16.
+// --------------------------------------------------------------------------
+template <int HLPL>
+__global__ __launch_bounds__(256) void topk_merge_sel_kernel(MergeArgs<int> a) {
+  __shared__ uint64_t compact[4][64];
+  __shared__ int sel_list[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+  if (qi >= a.nq) return;
+  const int ng_ = a.ngroups > 1 ? a.ngroups : 1, grp = (int)blockIdx.y;
+  if (a.zero_cnt && lane == 0 && grp == 0) {
+    a.zero_cnt[qi] = 0;
+    if (qi == 0) a.zero_cnt[a.nq] = 0;
+  }
+  const int nl = (a.nlists - grp + ng_ - 1) / ng_;
+  const int64_t gout = (int64_t)grp * a.nq;
+  // (a) heads: slot j of lane l = list l + 64 j of this group, as TRUE keys (a tie between heads must resolve by
+  //     row index exactly as in the final order); the kout-th largest head key is then the admission bar
+  uint64_t hk[HLPL];
+#pragma unroll
+  for (int j = 0; j < HLPL; ++j) {
+    const int list = lane + 64 * j;
+    hk[j] = 0ull;
+    if (list < nl) {
+      const int64_t o = ((int64_t)(list * ng_ + grp) * a.nq + qi) * a.kin;
+      hk[j] = merge_key(a.vals[o], a.idx[o]);
+    }
+  }
+  uint64_t mine;
+  int rank;
+  const int nsel = select_keys<HLPL>(hk, a.kout, lane, compact[wave], mine, rank);
+  if (lane < nsel && rank == nsel - 1) compact[wave][0] = mine;   // the bar (keys are unique: one lane writes)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const uint64_t bar = nsel > 0 ? compact[wave][0] : ~0ull;
+  int nlist = 0;
+#pragma unroll
+  for (int j = 0; j < HLPL; ++j) {
+    const bool sel = hk[j] != 0ull && hk[j] >= bar;
+    const uint64_t m = __ballot(sel);
+    if (sel) sel_list[wave][nlist + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = lane + 64 * j;
+    nlist += __builtin_popcountll(m);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // (b) the entries of the selected lists: entry e = lane + 64 j -> list e / 16, position e % 16
+  uint64_t kq[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + 64 * j;
+    kq[j] = 0ull;
+    if ((e >> 4) < nlist) {
+      const int list = sel_list[wave][e >> 4];
+      const int64_t o = ((int64_t)(list * ng_ + grp) * a.nq + qi) * a.kin + (e & 15);
+      kq[j] = merge_key(a.vals[o], a.idx[o]);
+    }
+  }
+  // (c)
+  const int k = select_keys<4>(kq, a.kout, lane, compact[wave], mine, rank);
+  if (lane < a.kout) {
+    const bool have = lane < k;
+    const int slot = have ? rank : lane;
+    const float wv = have ? merge_key_val(mine) : kNegInf;
+    const int wi = have ? merge_key_idx(mine) : -1;
+    a.out_val[(gout + qi) * a.kout + slot] = wv;
+    if (a.out_idx) a.out_idx[(gout + qi) * a.kout + slot] = have ? (int64_t)wi + a.idx_base : -1;
+    if (a.out_idx32) a.out_idx32[(gout + qi) * a.kout + slot] = wi;
+    if (slot == a.kout - 1) {
+      if (a.kth_val) a.kth_val[gout + qi] = wv;
+      if (a.kth_idx) a.kth_idx[gout + qi] = wi;
+    }
   }
 }
 
@@ -1306,7 +1401,12 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
   const int* fallback_gate = nullptr;
   bool prefix_done = false;
   int64_t cand_prefix = 0;
-  if (p.npass == 1 && p.prefix < ng && nq <= 128) {
+  // Same-box A/B against the list-keeping flow (tools/ab_sim.py, 1 M x 768 fp16, k = 16): 1 query 313 -> 302 us,
+  // 32 queries 327 -> 318 us, but 64 queries 333 -> 352 us and 128 queries 443 -> 453 us (two query tiles per wave:
+  // the list kernel's main scan is as fast there, and the flow adds two gated launches): k <= 16 takes the
+  // candidate flow up to 32 queries only.  k > 16 (1.25 M x 1024, top-50): 1001 -> 639 us at 32 queries,
+  // 1662 -> 742 us at 64: always.
+  if (p.npass == 1 && p.prefix < ng && nq <= 128 && (k > 16 || nq <= 32)) {
     const int G = k <= 16 ? 1 : (k + 15) / 16;
     int cap = k <= 16 ? kCandCap : kCandCapBig;
     Plan pc = p;
@@ -1359,7 +1459,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m.kth_val = w.floor_val;
       m.zero_cnt = w.cand_cnt;
       m.ngroups = G;
-      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid, G), dim3(256), 0, st, m);
+      hipLaunchKernelGGL(topk_merge_sel_kernel<kMergeLPL>, dim3(merge_grid, G), dim3(256), 0, st, m);
       HCIR_LAUNCH_CHECK();
       int* overflow = w.cand_cnt + nq;
       c.row_begin = G == 1 ? S : 0;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void add_f32_f16_kernel(const float* __restric
 // and the workgroup's partial sums  dgamma_part[wg][c] = sum_rows dy xhat,  dbeta_part[wg][c] = sum_rows dy.
 constexpr int kLnMaxJ = 16;  // d <= 4 * 64 * 16 = 4096
 
-template <typename XT>
+template <typename XT, int NJ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict__ x, int64_t ldx,
                                                             const _Float16* __restrict__ dy, int64_t lddy,
                                                             const float* __restrict__ gamma, float eps, int64_t rows,
@@ -82,11 +82,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
                                                             float* __restrict__ dbeta_part) {
   __shared__ float red[4][2];
   extern __shared__ float colacc[];  // [2][d] per workgroup, combined across the 4 waves at the end
+  // NJ = column groups of 256 per row, a compile-time bound: with a run-time bound the per-lane arrays (4 x 16 x 4
+  // floats) went to scratch and the kernel ran 5x off its HBM time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nj = (d + 255) / 256;
-  float gsum[kLnMaxJ][4], bsum[kLnMaxJ][4];
+  constexpr int nj = NJ;
+  float gsum[NJ][4], bsum[NJ][4];
 #pragma unroll
-  for (int j = 0; j < kLnMaxJ; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) gsum[j][e] = bsum[j][e] = 0.f;
   (void)red;
@@ -94,24 +96,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const XT* xr = x + row * ldx;
     const _Float16* dr = dy + row * lddy;
-    float xv[kLnMaxJ][4], dv[kLnMaxJ][4];
+    float xv[NJ][4], dv[NJ][4];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < kLnMaxJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (j < nj) {
         const int c = 4 * (lane + 64 * j);
+        if (c < d) {
+          if constexpr (sizeof(XT) == 2) {
+            const f16x4 xq = *reinterpret_cast<const f16x4*>(xr + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xv[j][e] = c < d ? (float)xr[c + e] : 0.f;
-          dv[j][e] = c < d ? (float)dr[c + e] : 0.f;
-          s += xv[j][e];
+            for (int e = 0; e < 4; ++e) xv[j][e] = (float)xq[e];
+          } else {
+            const f32x4 xq = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[j][e] = xq[e];
+          }
+          const f16x4 dq = *reinterpret_cast<const f16x4*>(dr + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dv[j][e] = (float)dq[e];
+            s += xv[j][e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[j][e] = dv[j][e] = 0.f;
         }
       }
     }
     const float mean = wave_sum(s) / (float)d;
     float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < kLnMaxJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (j < nj) {
         const int c = 4 * (lane + 64 * j);
 #pragma unroll
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
     const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int j = 0; j < kLnMaxJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (j < nj) {
         const int c = 4 * (lane + 64 * j);
         if (c < d) {
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
     }
     const float mg = wave_sum(sg) / (float)d, mgx = wave_sum(sgx) / (float)d;
 #pragma unroll
-    for (int j = 0; j < kLnMaxJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (j < nj) {
         const int c = 4 * (lane + 64 * j);
         if (c < d) {
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int j = 0; j < kLnMaxJ; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (j < nj) {
           const int c = 4 * (lane + 64 * j);
           if (c < d) {
@@ -187,14 +203,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
   }
 }
 
-// out[c] (+)= sum_p part[p][c], p in index order
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int parts, int n, float* __restrict__ out,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out[c] (+)= sum_p part[p][c]: workgroup = 64 columns x 4 part lanes (lane q sums parts q, q + 4, ... in order, the
+// four sums are then added in lane order: a fixed tree, deterministic); blockIdx.y selects one of `narr` independent
+// (part, out) pairs laid out back to back (LayerNorm: dgamma and dbeta in one launch).  A one-thread-per-column loop
+// over ~800 partial rows took 105 us per call (13 % of a training step's GPU time).
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int n,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const float* src = part + (int64_t)blockIdx.y * parts * n;
+  float* out = blockIdx.y == 0 ? out0 : out1;
   float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += part[(int64_t)p * n + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < n)
+    for (int p = pl; p < parts; p += 4) s += src[(int64_t)p * n + c];
+  red[pl][cl] = s;
+  __syncthreads();
+  if (pl == 0 && c < n) {
+    const float t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------- column sums of an fp16 matrix (bias gradients)
@@ -353,7 +382,7 @@ int hcir_add_f32_f16(const float* a, const float* b, int64_t n, void* y, void* s
 
 int32_t hcir_layernorm_bwd_blocks(int64_t rows) {
   int64_t b = hcir_cdiv(rows, 4 * 16);  // >= 16 rows per wave
-  return (int32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  return (int32_t)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx, const void* dy_f16,
@@ -371,19 +400,29 @@ int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int6
   float* bpart = workspace + (size_t)blocks * d;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t shm = (size_t)2 * d * sizeof(float);
+#define LNB(XT, NJV)                                                                                                \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<XT, NJV>), dim3(blocks), dim3(256), shm, st, static_cast<const XT*>(x), ldx, \
+                     static_cast<const _Float16*>(dy_f16), lddy, gamma, eps, rows, d, dres_in, dres_out, ldr, gpart,  \
+                     bpart)
+#define LNB_NJ(XT)                       \
+  do {                                   \
+    if (nj <= 1) LNB(XT, 1);             \
+    else if (nj <= 2) LNB(XT, 2);        \
+    else if (nj <= 3) LNB(XT, 3);        \
+    else if (nj <= 4) LNB(XT, 4);        \
+    else if (nj <= 8) LNB(XT, 8);        \
+    else LNB(XT, 16);                    \
+  } while (0)
+  const int nj = (d + 255) / 256;
   if (x_dtype == HCIR_F32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), shm, st, static_cast<const float*>(x), ldx,
-                       static_cast<const _Float16*>(dy_f16), lddy, gamma, eps, rows, d, dres_in, dres_out, ldr, gpart,
-                       bpart);
+    LNB_NJ(float);
   else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<_Float16>, dim3(blocks), dim3(256), shm, st,
-                       static_cast<const _Float16*>(x), ldx, static_cast<const _Float16*>(dy_f16), lddy, gamma, eps,
-                       rows, d, dres_in, dres_out, ldr, gpart, bpart);
+    LNB_NJ(_Float16);
+#undef LNB_NJ
+#undef LNB
   HCIR_LAUNCH_CHECK();
-  const dim3 fg((unsigned)hcir_cdiv(d, 256));
-  hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, st, gpart, blocks, d, dgamma, accumulate);
-  HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, fg, dim3(256), 0, st, bpart, blocks, d, dbeta, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 64), 2), dim3(256), 0, st, gpart, blocks, d,
+                     dgamma, dbeta, accumulate);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }
@@ -404,8 +443,8 @@ int hcir_colsum_f16(const void* x, int64_t m, int32_t n, int64_t ldx, float* out
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hcir_cdiv(n, 256), (unsigned)chunks), dim3(256), 0, st,
                      static_cast<const _Float16*>(x), m, n, ldx, rows_per, workspace);
   HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 256)), dim3(256), 0, st, workspace, chunks, n,
-                     out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 64), 1), dim3(256), 0, st, workspace, chunks, n,
+                     out, out, accumulate);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

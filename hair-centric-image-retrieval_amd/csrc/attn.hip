@@ -223,19 +223,180 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// --------------------------------------------------------------------------
+// Any head_dim that is a multiple of 16 up to 128 (vit_huge_patch14: 1280 / 16 = 80, HP/src/models_vit.py:266-270).
+// Same algorithm and MFMA operand maps as attn_fwd_kernel; correctness-first staging: K and V go through registers
+// into plain (unswizzled) LDS images, K rows HD * 2 bytes, V rows padded with zeros to a multiple of 32 dims so that
+// the O^T = V^T . P tiles of 32 dims need no edge case (the padded output rows are computed and not stored).
+// The tuned head_dim-64 kernel above is what every BASELINE config runs.
+// --------------------------------------------------------------------------
+template <int HD, int NKT>
+__global__ __launch_bounds__(256, 1) void attn_fwd_generic_kernel(AttnArgs a) {
+  constexpr int TP = 32 * NKT;
+  constexpr int HDP = (HD + 31) / 32 * 32;     // V / output dims padded to whole 32-row MFMA tiles
+  constexpr int KPB = HD * 2, VPB = HDP * 2;   // row pitches in bytes
+  constexpr int NS = HD / 16, NDT = HDP / 32;
+  static_assert(HD % 16 == 0 && HD <= 128, "head_dim");
+  __shared__ __attribute__((aligned(16))) char lds[TP * (KPB + VPB)];
+  char* ks = lds;
+  char* vs = lds + TP * KPB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x % a.h;
+  const int64_t b = blockIdx.x / a.h;
+  const int64_t row_stride = (int64_t)3 * a.h * HD;
+  const _Float16* base = a.qkv + b * a.t * row_stride + head * HD;
+  const _Float16* qg = base;
+  const _Float16* kg = base + (int64_t)a.h * HD;
+  const _Float16* vg = base + (int64_t)2 * a.h * HD;
+  for (int slot = tid; slot < TP * (HDP / 8); slot += 256) {
+    const int key = slot / (HDP / 8), c = slot % (HDP / 8);
+    const int src_key = key < a.t ? key : a.t - 1;
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (c * 8 < HD) {
+      kv = *reinterpret_cast<const u32x4*>(kg + src_key * row_stride + c * 8);
+      vv = *reinterpret_cast<const u32x4*>(vg + src_key * row_stride + c * 8);
+      *reinterpret_cast<u32x4*>(ks + key * KPB + c * 16) = kv;
+    }
+    *reinterpret_cast<u32x4*>(vs + key * VPB + c * 16) = vv;
+  }
+  __syncthreads();
+  const int nqt = (a.nq + 31) >> 5;
+  const float ninf = -__builtin_huge_valf();
+  const int grp = lane >> 4, li = lane & 15;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q0 = qt * 32;
+    int qrow = q0 + r;
+    qrow = qrow < a.t ? qrow : a.t - 1;
+    f16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const f16x8*>(qg + qrow * row_stride + 16 * s + 8 * h);
+    f32x16 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+      const int key = kt * 32 + r;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(ks + key * KPB + (2 * s + h) * 16);
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kt], 0, 0, 0);
+      }
+    }
+    float mx = ninf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = (NKT - 1) * 32 + acc_row(i, h);
+      sc[NKT - 1][i] = key < a.t ? sc[NKT - 1][i] : ninf;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mxs = mx * a.scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], a.scale_log2e, -mxs));
+        sc[kt][i] = p;
+        sum += p;
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int t2 = 0; t2 < NDT; ++t2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sc[kt][8 * s + j];
+#pragma unroll
+        for (int hdt = 0; hdt < NDT; ++hdt) {
+          const int c0 = 32 * hdt + 16 * (grp & 1) + 4 * (li & 3);
+          const int kb = 32 * kt + 16 * s + 4 * (grp >> 1) + (li >> 2);
+          f16x8 vf;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int key = kb + 8 * half;
+            const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (fp16x4_t __attribute__((address_space(3)))*)(vs + key * VPB + c0 * 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vf[4 * half + e] = (_Float16)v4[e];
+          }
+          oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[hdt], 0, 0, 0);
+        }
+      }
+    }
+    const int q = q0 + r;
+    if (q < a.nq) {
+      _Float16* orow = a.out + (b * a.nq + q) * ((int64_t)a.h * HD) + head * HD;
+#pragma unroll
+      for (int hdt = 0; hdt < NDT; ++hdt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int dim = 32 * hdt + 8 * g4 + 4 * h;
+          if (dim < HD) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
+            *reinterpret_cast<f16x4*>(orow + dim) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int HD>
+static int attn_generic_launch(const AttnArgs& a, int nqt, dim3 grid, hipStream_t st) {
+#define LAUNCHG(N) hipLaunchKernelGGL((attn_fwd_generic_kernel<HD, N>), grid, dim3(256), 0, st, a)
+  switch (nqt) {
+    case 1: LAUNCHG(1); break;
+    case 2: LAUNCHG(2); break;
+    case 3: LAUNCHG(3); break;
+    case 4: LAUNCHG(4); break;
+    case 5: LAUNCHG(5); break;
+    case 6: LAUNCHG(6); break;
+    case 7: LAUNCHG(7); break;
+    case 8: LAUNCHG(8); break;
+    default: LAUNCHG(9); break;
+  }
+#undef LAUNCHG
+  return 0;
+}
+
 }  // namespace
 
 static int attn_fwd_launch(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale, int32_t nq,
                            void* out, float* lse, void* stream) {
   HCIR_ENTER();
   if (!qkv || !out || b <= 0 || t <= 0 || h <= 0 || nq <= 0 || nq > t) return HCIR_ERR_INVALID;
-  if (hd != 64 || t > 288) return HCIR_ERR_UNSUPPORTED;
+  if (t > 288) return HCIR_ERR_UNSUPPORTED;
+  if (hd != 64 && (lse || (hd != 32 && hd != 48 && hd != 80 && hd != 96 && hd != 128))) return HCIR_ERR_UNSUPPORTED;
   if (b * h > 0x7fffffff) return HCIR_ERR_INVALID;
   AttnArgs a{static_cast<const _Float16*>(qkv), static_cast<_Float16*>(out), t, h, nq,
              scale * 1.44269504088896340736f, lse};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nqt = (t + 31) / 32;
   const dim3 grid((unsigned)(b * h));
+  if (hd != 64) {   // generic (unswizzled, register-staged) kernel
+    if (hd == 32) attn_generic_launch<32>(a, nqt, grid, st);
+    else if (hd == 48) attn_generic_launch<48>(a, nqt, grid, st);
+    else if (hd == 80) attn_generic_launch<80>(a, nqt, grid, st);
+    else if (hd == 96) attn_generic_launch<96>(a, nqt, grid, st);
+    else attn_generic_launch<128>(a, nqt, grid, st);
+    HCIR_LAUNCH_CHECK();
+    return HCIR_OK;
+  }
 #define LAUNCH(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), 0, st, a)
   // the kernel is built for NKT key tiles; 4 waves walk the query tiles
   switch (nqt) {

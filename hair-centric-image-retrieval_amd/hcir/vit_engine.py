@@ -119,8 +119,8 @@ class VitEngine:
         self._resid_epi = _lib.EPI_BIAS_RESID_F32 if resid_dtype == torch.float32 else _lib.EPI_BIAS_RESID_F16
         if device.type != "cuda":
             raise HcirError(f"VitEngine needs a HIP device, got {device} (no CPU fallback)")
-        if spec.dim % spec.heads or spec.dim // spec.heads != 64:
-            raise HcirError("hcir_attn_fwd supports head_dim 64")
+        if spec.dim % spec.heads or spec.dim // spec.heads not in (32, 48, 64, 80, 96, 128):
+            raise HcirError("hcir_attn_fwd supports head_dim 32, 48, 64 (tuned), 80, 96, 128")
         self.L = _lib.lib()
         self.device = device
         self.dim, self.heads, self.eps, self.pos_mult = spec.dim, spec.heads, float(spec.eps), float(spec.pos_mult)

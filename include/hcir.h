@@ -221,7 +221,8 @@ int hcir_patch_embed(const float* img, int64_t b, int32_t c, int32_t h, int32_t 
  * K and V of one (b, head) are LDS-resident; QK^T and PV are MFMA 32x32x16
  * tiles; softmax stays in registers.  (HP/src/models_vit.py:69-78;
  * nn.MultiheadAttention inside torchvision EncoderBlock, HP/src/main_backbone.py:554.)
- * Requirements: hd == 64, T <= 288. */
+ * Requirements: T <= 288; hd == 64 runs the tuned kernel, hd in {32, 48, 80, 96, 128} (vit_huge_patch14: 80,
+ * HP/src/models_vit.py:266-270) a generic one with unswizzled, register-staged LDS images. */
 int hcir_attn_fwd(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd,
                   float scale, int32_t nq, void* out, void* stream);
 

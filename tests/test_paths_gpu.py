@@ -173,6 +173,29 @@ def test_vit_large_patch14_fused_path(monkeypatch):
     assert _cos_err(outs[True].reshape(-1, 1024), outs[False].reshape(-1, 1024)) <= 1e-4
 
 
+def test_vit_huge_geometry_head_dim_80():
+    """vit_huge_patch14's geometry (embed 1280, 16 heads -> head_dim 80, patch 14; HP/src/models_vit.py:266-270) at a
+    depth of 2 (the 32-block model is 632 M parameters): forward_features against the oracle."""
+    from functools import partial
+    from hcir.models_vit import LayerNorm, VisionTransformer
+    torch.manual_seed(7)
+    m = VisionTransformer(patch_size=14, embed_dim=1280, depth=2, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                          norm_layer=partial(LayerNorm, eps=1e-6), drop_path_rate=0.0, global_pool=True,
+                          init_values=None).eval()
+    with torch.no_grad():
+        m.pos_embed.normal_(0, 0.02)
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and "norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape))
+    x = torch.randn(2, 3, 224, 224)
+    ref = ovit.models_vit_forward_features({k: v.clone() for k, v in m.state_dict().items()}, x, num_heads=16)
+    m = m.cuda()
+    with torch.no_grad():
+        out = m.forward_features(x.cuda())
+    assert out.shape == (2, 257, 1280)
+    assert _cos_err(out.float().cpu(), ref) <= 1e-3
+
+
 def test_mae_extract_features():
     from hcir.backbone import MAE, vit_base_patch16_224
     torch.manual_seed(9)

@@ -205,6 +205,24 @@ def test_attention(L, b, t, h):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
 
 
+@pytest.mark.parametrize("b,t,h,hd", [(2, 257, 16, 80), (1, 197, 3, 128), (3, 33, 2, 32), (1, 288, 2, 96), (2, 50, 4, 48)])
+def test_attention_other_head_dims(L, b, t, h, hd):
+    """head_dim != 64 (vit_huge_patch14: 1280 / 16 = 80, HP/src/models_vit.py:266-270): the generic kernel."""
+    g = torch.Generator().manual_seed(b * 100 + t + h + hd)
+    qkv = (torch.randn(b, t, 3, h, hd, generator=g) * 1.2).half()
+    q, k, v = [qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3)]
+    scale = hd ** -0.5
+    ref = (torch.softmax((q * scale) @ k.transpose(-2, -1), -1) @ v).permute(0, 2, 1, 3).reshape(b, t, h * hd)
+    out = torch.full((b, t, h * hd), float("nan"), dtype=torch.float16, device="cuda")
+    qd = qkv.cuda()
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, scale, t, out.data_ptr(), _st()) == 0
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
+    part = torch.empty(b, 1, h * hd, dtype=torch.float16, device="cuda")
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, hd, scale, 1, part.data_ptr(), _st()) == 0
+    assert torch.equal(part, out[:, :1])
+    assert L.hcir_attn_fwd(qd.data_ptr(), b, t, h, 72, scale, t, out.data_ptr(), _st()) == -2   # unsupported
+
+
 def test_attention_query_row_limit(L):
     """nq < T: only the first nq query rows are computed, written compactly [B][nq][H*hd]."""
     b, t, h, hd = 3, 197, 12, 64

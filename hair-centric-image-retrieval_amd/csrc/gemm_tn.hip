@@ -176,7 +176,9 @@ TnPlan tn_plan(int64_t m, int n, int k) {
   p.tiles_k = k / 256;
   const int tiles = p.tiles_n * p.tiles_k;
   const int64_t steps = m / 64;
-  int64_t splits = (256 + tiles - 1) / tiles;  // about one workgroup per CU
+  // one workgroup per CU (128 KB of LDS each) and never more than 256 in all: a grid of 270 runs as one full round
+  // plus a nearly empty one (27 tiles x 10 splits took twice the time of 27 x 9)
+  int64_t splits = 256 / tiles;
   splits = splits > steps ? steps : splits;
   splits = splits < 1 ? 1 : splits;
   p.rows_per_split = hcir_cdiv(steps, splits) * 64;

@@ -112,17 +112,17 @@ def test_transform_matches_oracle(golden_dir):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r1_final_bench.json is a verbatim bench.py line: it must carry every key of the bench contract
+    """profiles/r2_bench.json is a verbatim bench.py line: it must carry every key of the bench contract
     (metric/config of BASELINE.json, roofline and cpu_baseline objects) with sane values."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r1_final_bench.json")) as f:
+    with open(os.path.join(root, "profiles", "r2_bench.json")) as f:
         line = json.load(f)
     with open(os.path.join(root, "BASELINE.json")) as f:
         base = json.load(f)
     assert line["metric"] == base["metric"]
     for key in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "batch_sweep"):
         assert key in line, key
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
@@ -133,6 +133,9 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1 and r["traffic"] is not None
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    par = line["parity"]
+    assert par["max_1mcos"] <= par["tolerance_1mcos"] == 1e-3 and par["top10_index_match_scan"] == 1.0
+    assert set(line["batch_sweep"]) >= {"64", "880"} and "vendor_yardstick_tflops" in r
 
 
 def test_hair_retrieval_cli_flags_and_image_folder(tmp_path, golden_dir):

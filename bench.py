@@ -328,15 +328,20 @@ def main():
         for _ in range(5):
             ops.sim_topk(scan_q, scan_g, scan_k, idx_base=lo)
         ev[1].record()
-        # streaming design point of the same kernel: 64 queries (HBM-bound), not part of `value`
-        ops.sim_topk(scan_q[:64].contiguous(), scan_g, scan_k, idx_base=lo)
-        ev[2].record()
-        for _ in range(5):
-            ops.sim_topk(scan_q[:64].contiguous(), scan_g, scan_k, idx_base=lo)
-        ev[3].record()
-        torch.cuda.synchronize()
+        # streaming design points of the same kernel (HBM-bound: 64, 32, 1 queries), not part of `value`
+        stream_ms = {}
+        for nqs in (64, 32, 1):
+            qs = scan_q[:nqs].contiguous()
+            ops.sim_topk(qs, scan_g, scan_k, idx_base=lo)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.sim_topk(qs, scan_g, scan_k, idx_base=lo)
+            e1.record()
+            torch.cuda.synchronize()
+            stream_ms[nqs] = e0.elapsed_time(e1) / 10
         sim_ms = ev[0].elapsed_time(ev[1]) / 5
-        sim64_ms = ev[2].elapsed_time(ev[3]) / 5
+        sim64_ms = stream_ms[64]
         scan_esize = scan_g.element_size()
 
     # ---- PCIe-inclusive rate (NOT `value`): the same step fed from pinned host memory, the copy of batch i+1 on a
@@ -470,6 +475,11 @@ def main():
                                                            "traffic": scan_traffic if (args.gallery == 1_000_000 and world == 1 and scan_esize == 2) else None,
                                                            "note": "same kernel + merges at its HBM-bound design "
                                                                    "point (64 queries); not part of `value`"},
+                                  "streaming_fewer_queries": {
+                                      str(nqs): {"ms": stream_ms[nqs],
+                                                 "frac": (shard.shape[0] * 768 * scan_esize + nqs * 768 * scan_esize + nqs * scan_k * 12)
+                                                         / (stream_ms[nqs] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                      for nqs in (32, 1)},
                                   "filter_stats": None if resident is None else dict(resident.stats)},
             "roofline_attn": {"kernel": "attn_fwd_kernel", "bound": "mfma",
                               "achieved": attn_f / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,

@@ -515,6 +515,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 // MFMAs per wave) to land.  Stages run on across tile boundaries: the next tile's first
 // stage flies under the epilogue.  Requires K % 64 == 0.
 // ---------------------------------------------------------------------------
+#ifdef HCIR_DIAG_GSTAMPS
+// diagnostic build only (tools/diag_gemm_stamps.py): 100 MHz wall-clock stamps around the SECOND tile of every
+// workgroup of the 256 x 256 kernel
+__device__ unsigned long long g_gemm_stamps[256 * 8];
+#define HCIR_GSTAMP(cond, i)                                                                   \
+  do {                                                                                         \
+    if ((cond) && threadIdx.x == 0 && blockIdx.x < 256)                                        \
+      g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                  \
+  } while (0)
+#else
+#define HCIR_GSTAMP(cond, i) \
+  do {                       \
+  } while (0)
+#endif
+
+#ifndef HCIR_GEMM_NGROUP
+#define HCIR_GEMM_NGROUP 3  // tools/ab_gemm.py, batch 880: fc1 908 -> 890 us, qkv 574 -> 568 us (0 = n fastest over the whole N)
+#endif
+
 struct G256 {
   static constexpr int NT = 512;
   static constexpr int ROWS = 512;               // 256 W rows (n) then 256 activation rows (m)
@@ -537,6 +556,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
 
   auto tile_origin = [&](int ti, int& n0, int64_t& m0) {
     const int t = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
+#if HCIR_GEMM_NGROUP > 0
+    // n-grouped order: the W panels of one group of HCIR_GEMM_NGROUP n-tiles stay in the XCD's L2 while every
+    // m-tile streams past them (a W set wider than the 4 MB L2 - fc1: 12 panels, 4.7 MB - is otherwise re-fetched
+    // for every row of tiles)
+    if (tiles_n % HCIR_GEMM_NGROUP == 0 && tiles_n > HCIR_GEMM_NGROUP) {
+      const int per = HCIR_GEMM_NGROUP * tiles_m;
+      const int grp = t / per, rem = t - grp * per;
+      n0 = (grp * HCIR_GEMM_NGROUP + rem % HCIR_GEMM_NGROUP) * 256;
+      m0 = (int64_t)(rem / HCIR_GEMM_NGROUP) * 256;
+      return;
+    }
+#endif
     n0 = (t % tiles_n) * 256;
     m0 = (int64_t)(t / tiles_n) * 256;
   };
@@ -607,9 +638,25 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
   }
 
   int kc = 0, ti = 0;
+#ifdef HCIR_GEMM_STORE_DRAIN
+  bool landed = false;  // stage `step` was waited for before the previous tile's epilogue
+#endif
   for (int step = 0; step < nsteps; ++step) {
+#ifdef HCIR_GEMM_STORE_DRAIN
+    if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed = false;
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
+    HCIR_GSTAMP(ti == 1 && kc == 0, 0);
+    HCIR_GSTAMP(ti == 2 && kc == 0, 4);
+#ifdef HCIR_DIAG_GSTAMPS
+    // shader-clock counter at the same two points: (s_memtime delta) / (s_memrealtime delta) x 100 MHz = the clock
+    // the chip holds inside the kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
+    if (kc == 0 && (ti == 1 || ti == 2) && threadIdx.x == 0 && blockIdx.x < 256)
+      g_gemm_stamps[blockIdx.x * 8 + (ti == 1 ? 6 : 7)] = __builtin_amdgcn_s_memtime();
+#endif
 
     const char* st = lds + (step & 1) * G256::STAGE_BYTES;
     const bool do_issue = step + 1 < nsteps;
@@ -668,16 +715,27 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       }
     }
     if (do_issue) issue_advance();
+    HCIR_GSTAMP(ti == 2 && kc == 0, 5);
 
     if (++kc == nkc) {
       int n0;
       int64_t m0;
       tile_origin(ti, n0, m0);
+      HCIR_GSTAMP(ti == 1, 1);
+#ifdef HCIR_GEMM_STORE_DRAIN
+      // The next tile's first stage was issued early in this step: wait for it HERE, before the epilogue's stores
+      // join the same counter, so that the step behind the epilogue starts on a barrier alone and the store
+      // acknowledgements (1.3 - 4 us per tile when that step's vmcnt(0) waited for them) drain under its MFMAs.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      landed = step + 1 < nsteps;
+#endif
       // all waves are done reading slot step&1 (their MFMAs have consumed it) after this barrier;
       // the slot stays free until the DMA of stage step+2 is issued behind the next step's barrier
       __builtin_amdgcn_s_barrier();
+      HCIR_GSTAMP(ti == 1, 2);
       gemm_epilogue256_lds<EPI, MF16>(g, acc, lds + (step & 1) * G256::STAGE_BYTES + wave * 8192,
                                       m0 + wave_m * 64, n0 + wave_n * 128, lane);
+      HCIR_GSTAMP(ti == 1, 3);
       acc.zero();
       kc = 0;
       ++ti;
@@ -1329,6 +1387,12 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }
+
+#ifdef HCIR_DIAG_GSTAMPS
+int hcir_debug_gemm_stamps(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 int hcir_gemm_fused_supported(int64_t m, int32_t n, int32_t k) { return gemm_takes_big(m, n, k) ? 1 : 0; }
 

@@ -31,6 +31,21 @@
 #define HCIR_SCAN_AUX 2  // cache policy of the once-read gallery stream: 2 = nt (non-temporal), +5 % GB/s
 #endif
 
+#ifdef HCIR_DIAG_STAMPS
+// diagnostic build only (tools/build_variant.sh stamps "-DHCIR_DIAG_STAMPS"): wall-clock stamps (100 MHz) of the
+// floorless (prefix) launches, 8 per workgroup, read back through hcir_debug_stamps
+__device__ unsigned long long g_stamps[1024 * 8];
+#define HCIR_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (!a.floor_val && threadIdx.x == 0 && blockIdx.x < 512)                                      \
+      g_stamps[(blockIdx.y * 512 + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();     \
+  } while (0)
+#else
+#define HCIR_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+
 namespace {
 
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -77,6 +92,44 @@ __device__ __forceinline__ float merge_key_val(uint64_t k) {
 }
 __device__ __forceinline__ int merge_key_idx(uint64_t k) { return (int)(0xFFFFFFFFu - (uint32_t)k); }
 
+// Batch insertion (scan epilogue): when many of a lane's 16 scores of one 32 x 32 MFMA tile are candidates - every
+// one of them while the lists fill from a workgroup's first tile - the slot-by-slot insertion costs ~115 VALU
+// instructions per slot for the whole wave.  The batch path sorts the 16 keys with a bitonic network (80
+// compare-exchanges), takes max(list[j], batch[KP-1-j]) - the KP best of the union, as a bitonic sequence - and
+// finishes with one bitonic merge: ~130 (KP = 16) compare-exchanges of 5 instructions, whatever the number of
+// candidates.  Keys are merge_key's (score, row) words: all distinct, so the network needs no stability.
+__device__ __forceinline__ void key_ce_desc(uint64_t& a, uint64_t& b) {  // a <- better, b <- worse
+  const bool sw = b > a;
+  const uint64_t t = sw ? b : a;
+  b = sw ? a : b;
+  a = t;
+}
+template <int N>
+__device__ __forceinline__ void key_bitonic_merge_desc(uint64_t (&x)[N]) {  // bitonic -> sorted, best first
+#pragma unroll
+  for (int st = N / 2; st >= 1; st >>= 1)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if ((i & st) == 0) key_ce_desc(x[i], x[i + st]);
+}
+__device__ __forceinline__ void key_bitonic_sort16_desc(uint64_t (&x)[16]) {
+#pragma unroll
+  for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          if ((i & k) == 0)
+            key_ce_desc(x[i], x[l]);
+          else
+            key_ce_desc(x[l], x[i]);
+        }
+      }
+}
+constexpr int kBatchMin = 8;  // candidates slots (wave union) from which the batch path is taken
+
 struct ScanArgs {
   const void* q;
   const void* g;
@@ -101,7 +154,13 @@ struct ScanArgs {
   int floor_inclusive;  // 1: candidates are scores >= floor (the scan covers the rows the floor came from)
 };
 
-template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS, bool CAND = false>
+// BATCH: the launch fills its lists from nothing (no floor: prefix scans, single scans of small galleries, the
+// k > 64 passes) - the epilogue gets the batch-insertion path.  A separate instantiation, and only of the
+// one-query-tile geometry: the path's ~100 extra live registers spill in the two-query-tile kernels at two
+// workgroups per CU (measured: the 64-query main scan 260 -> 780 us) and at one workgroup per CU they lose what the
+// batch gains (64-query call 333 -> 340 us); running a 64-query prefix as two 32-query blocks of this kernel was a
+// wash (prefix 52 -> 49 us).  The streaming launches behind a floor keep the lean kernel.
+template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS, bool CAND = false, bool BATCH = false>
 __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
   using Cfg = SimCfg<T, WGG, WQ, QT>;
   constexpr int EPS = SimElem<T>::kPerStage;
@@ -119,6 +178,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
   __shared__ __attribute__((aligned(16))) char lds[NST * Cfg::STAGE_BYTES];
 
   if (a.gate && *a.gate == 0) return;  // uniform: every wave of the grid reads the same flag
+  HCIR_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_g = wave / WQ, wave_q = wave % WQ;
   const int r = lane & 31, h = lane >> 5;
@@ -251,6 +311,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     }
   }
   if constexpr (!GLDS) __syncthreads();
+  HCIR_STAMP(1);
 
   int64_t tile_i = 0;  // index among my tiles
   int kc = 0;
@@ -276,8 +337,10 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
         sim_glds_retire_and_sync();
       }
       // the slot read in step-1 is free after this barrier: issue stage step+NST-1 into it
+      if (step == 0) HCIR_STAMP(2);
       if (step + NST - 1 < nsteps) issue_stage((cur + NST - 1) % NST);
       sim_stage_mfma<T, Cfg, QT>(acc, lds + cur * Cfg::STAGE_BYTES, wave_g, wave_q, lane);
+      if (step == nsteps - 1) HCIR_STAMP(3);
     } else {
       if (has_next)
         sim_stage_load<T, Cfg>(regs, g, tile_row0(ntile_i), g_last, q, q_row0, q_last, a.d, nkc_next, tid);
@@ -326,6 +389,33 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
             for (int off = 32; off > 0; off >>= 1) any |= __shfl_xor(any, off);
             any = __builtin_amdgcn_readfirstlane(any);
           }
+          if constexpr (!CAND && BATCH) {
+            if (__builtin_popcount(any) >= kBatchMin) {  // wave-uniform
+              uint64_t bk[16];
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const bool c = ((mask >> i) & 1u) && acc[gt][qt][i] > thr[qt];
+                bk[i] = c ? merge_key(acc[gt][qt][i], (int)(rbase + (i & 3) + 8 * (i >> 2))) : 0ull;
+              }
+              key_bitonic_sort16_desc(bk);
+              uint64_t lk[KP];
+#pragma unroll
+              for (int j = 0; j < KP; ++j) lk[j] = merge_key(lv[qt][j], li[qt][j]);
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                const uint64_t o = bk[15 - j];
+                lk[KP - 16 + j] = o > lk[KP - 16 + j] ? o : lk[KP - 16 + j];
+              }
+              key_bitonic_merge_desc<KP>(lk);
+#pragma unroll
+              for (int j = 0; j < KP; ++j) {
+                lv[qt][j] = lk[j] ? merge_key_val(lk[j]) : kNegInf;
+                li[qt][j] = lk[j] ? merge_key_idx(lk[j]) : -1;
+              }
+              thr[qt] = fmaxf(floorv[qt], topk_kth<KP>(lv[qt], a.k));
+              any = 0u;
+            }
+          }
           while (any != 0u) {
             const int i = __builtin_ctz(any);
             any &= any - 1u;
@@ -357,6 +447,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     tile_i = ntile_i;
     cur = (cur + 1 == NST) ? 0 : cur + 1;
   }
+  HCIR_STAMP(4);
   if constexpr (!CAND) {  // (CAND: nothing to merge, the candidates are already in the per-query buffers)
   __syncthreads();  // every wave is done with the stage buffers before they are re-used below
 
@@ -435,6 +526,7 @@ __global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_sc
     __syncthreads();
   }
   }  // !CAND
+  HCIR_STAMP(5);
 }
 
 // --------------------------------------------------------------------------
@@ -1197,6 +1289,8 @@ inline int scan_grid_x(int64_t tiles, int64_t qblocks) {
   return (int)(tiles < cap ? tiles : cap);
 }
 
+// Prefix launches of 16-entry lists with 33..kPrefixQb32MaxQ queries run as 32-query blocks (the batch-insertion
+// kernel; the prefix is latency- and insertion-bound, not bandwidth-bound, and the blocks of a tile share its L2 lines).
 Plan make_plan(int64_t nq, int64_t ng, int k) {
   Plan p;
   p.kp = k <= 16 ? 16 : (k <= 32 ? 32 : 64);
@@ -1275,7 +1369,10 @@ Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
 
 template <typename T, int KP, int QT, int WQ, int WGG>
 void launch_scan_cfg(const ScanArgs& a, int grid_x, int grid_y, hipStream_t st) {
-  if (a.d % SimElem<T>::kPerStage == 0)
+  if (QT == 1 && a.d % SimElem<T>::kPerStage == 0 && !a.floor_val)
+    hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG, true, false, (QT == 1)>), dim3(grid_x, grid_y), dim3(256), 0,
+                       st, a);
+  else if (a.d % SimElem<T>::kPerStage == 0)
     hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG, true>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((sim_topk_scan<T, KP, QT, WQ, WGG, false>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
@@ -1351,6 +1448,12 @@ void launch_scan_dtype(int dtype, const Plan& p, const ScanArgs& a, int grid_x, 
 }  // namespace
 
 extern "C" {
+
+#ifdef HCIR_DIAG_STAMPS
+int hcir_debug_stamps(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 size_t hcir_sim_topk_workspace_bytes(int64_t nq, int64_t ng, int32_t d, int32_t k, int dtype) {
   (void)d;

@@ -1,7 +1,7 @@
 """A/B of libhcir builds at the ViT-B/16 GEMM shapes, interleaved rounds in ONE process
 (cdna_hip_programming.md §5.4 rule 24): every variant is a separately built .so of the same sources.
 
-usage: python3 tools/ab_gemm.py <batch> tag=path [tag=path ...]
+usage: python3 tools/ab_gemm.py <batch> tag=path [tag=path ...] [zeros]
        (tag 'base' = the in-tree library when no path is given: base=)
 Each shape: `rounds` rounds of {variant A x iters, variant B x iters, ...}; prints median and min us per variant.
 """
@@ -23,8 +23,9 @@ def load(path):
 
 def main():
     b = int(sys.argv[1])
+    zeros = "zeros" in sys.argv[2:]      # zero-filled operands: the clock the chip holds without data toggling
     libs = []
-    for spec in sys.argv[2:]:
+    for spec in [a for a in sys.argv[2:] if a != "zeros"]:
         tag, _, path = spec.partition("=")
         libs.append((tag, load(path or _lib.LIB_PATH)))
     m = b * 197
@@ -36,6 +37,8 @@ def main():
         a = (torch.randn(m, k, device="cuda") * 0.5).half()
         w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
         bias = torch.randn(n, device="cuda")
+        if zeros:
+            a.zero_(), w.zero_(), bias.zero_()
         out = torch.zeros(m, n, device="cuda", dtype=torch.float16)
         call = lambda L: L.hcir_gemm_f16(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, epi,
                                          out.data_ptr(), n, st)

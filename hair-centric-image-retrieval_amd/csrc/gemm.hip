@@ -185,10 +185,34 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
   constexpr int NB = kF16 ? 2 : 1;     // float4 of bias per lane per pass
   const int rrow = lane >> 3, rchunk = lane & 7;
 
-  // per-lane bias / scale of every pass, loaded once, retired once, then laundered
+  // 16x16x32 accumulators, fp16 outputs: bias / scale / activation / LayerNorm fold run on the ACCUMULATOR side, in
+  // fp32, before the one rounding to fp16 - the row side only moves 16-B pieces (and adds the fp16 residual).  The
+  // earlier form rounded the raw accumulator to fp16, widened it again behind the transposition, did the math
+  // there and rounded a second time: five VALU instructions per output pair instead of two, and the epilogue phase
+  // of a tile is VALU / LDS-issue time (in-kernel stamps: 4.6 us per qkv tile, 8.6 us per fc1 tile).
+  constexpr bool kAccSide = MF16 && kF16;
+  constexpr bool kScaleA = kAccSide && (EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH);
+  f32x4 biasA[kAccSide ? 8 : 1], scaleA[kScaleA ? 8 : 1];
+  bool has_scale = false;
+  if constexpr (kAccSide) {
+    has_scale = kScaleA && (EPI == HCIR_EPI_AFFINE_RELU_F16 || g.scale != nullptr);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int n = nbase + 16 * t + 4 * (lane >> 4);
+      biasA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (g.bias) biasA[t] = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if constexpr (kScaleA) {
+        scaleA[t] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (has_scale) scaleA[t] = *reinterpret_cast<const f32x4*>(g.scale + n);
+      }
+    }
+  }
+  // per-lane bias / scale of every pass (row side: fp32 outputs and the 32x32x16 variant), loaded once, retired
+  // once, then laundered
   f32x4 bias[NPASS][NB], scale[NPASS][NB];
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
+    if constexpr (kAccSide) break;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int n = nbase + pass * (kF16 ? 64 : 32) + rchunk * (kF16 ? 8 : 4) + 4 * j;
@@ -210,6 +234,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
   if constexpr (kLn) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
+      if constexpr (kAccSide) break;
       int64_t mm = m0w + it * 8 + rrow;
       mm = mm < g.m ? mm : g.m - 1;
       ln_rs[it] = g.ln_stats[2 * mm + 1];
@@ -219,28 +244,40 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
       int64_t mm = m0w + (MF16 ? 16 * mt + (lane & 15) : 32 * mt + r);
       mm = mm < g.m ? mm : g.m - 1;
       ln_mean[mt] = g.ln_stats[2 * mm];
+      if constexpr (kAccSide) ln_rs[mt] = g.ln_stats[2 * mm + 1];  // (the row-side rstd above is unused then)
     }
 #pragma unroll
     for (int t = 0; t < (MF16 ? 8 : 16); ++t)
       c1a[t] = *reinterpret_cast<const f32x4*>(
           g.ln_c1 + nbase + (MF16 ? 16 * t + 4 * (lane >> 4) : 32 * (t >> 2) + 8 * (t & 3) + 4 * h));
   }
+  // (Issuing the next tile's first stage from here, behind these constant loads and with vmcnt(8), instead of from
+  // inside the tile's last k-step - so that this wait does not sit out the rest of the stage's round trip - was
+  // measured: 3-5 % SLOWER on every shape, tools/ab_gemm.py; like the early-issue main loop, DESIGN.md "GEMM round 2".)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (kLn) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(ln_rs[it]));
+    for (int it = 0; it < (kAccSide ? 4 : 8); ++it) asm volatile("" : "+v"(ln_rs[it]));
 #pragma unroll
     for (int mt = 0; mt < (MF16 ? 4 : 2); ++mt) asm volatile("" : "+v"(ln_mean[mt]));
 #pragma unroll
     for (int t = 0; t < (MF16 ? 8 : 16); ++t) launder(c1a[t]);
   }
+  if constexpr (kAccSide) {
 #pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      launder(bias[pass][j]);
-      launder(scale[pass][j]);
+    for (int t = 0; t < 8; ++t) {
+      launder(biasA[t]);
+      if constexpr (kScaleA) launder(scaleA[t]);
     }
+  } else {
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        launder(bias[pass][j]);
+        launder(scale[pass][j]);
+      }
+  }
 
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -289,13 +326,33 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           for (int q = 0; q < 4; ++q) {   // 64 features per pass = 4 n-tiles of 16
             const int nt = 4 * pass + q;
             f16x4 o;
-            if constexpr (kLn) {
+            float xs[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)__builtin_fmaf(-ln_mean[mt], c1a[nt][e], acc.a[nt][mt][e]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc.a[nt][mt][e];
+            for (int e = 0; e < 4; ++e) {
+              float x = acc.a[nt][mt][e];
+              const float bb = biasA[nt][e];
+              if constexpr (kLn) {
+                // out = rstd[m] (acc - mean[m] c1[n]) + bias[n]: centered first (cancellation when |mean| >> std)
+                x = __builtin_fmaf(ln_rs[mt], __builtin_fmaf(-ln_mean[mt], c1a[nt][e], x), bb);
+              } else if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+                x = fmaxf(__builtin_fmaf(x, scaleA[nt][e], bb), 0.f);
+              } else if constexpr (kResidH) {
+                x = scaleA[nt][e] * (x + bb);
+              } else {
+                x += bb;
+              }
+              xs[e] = x;
             }
+            if constexpr (kGelu) {
+#pragma unroll
+              for (int e = 0; e < 4; e += 2) {
+                const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
+                xs[e] = y[0];
+                xs[e + 1] = y[1];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)xs[e];
             const int chunk = 2 * q + (q16 >> 1);
             *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
           }
@@ -331,6 +388,14 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           const int row = (it0 + u) * 8 + rrow;
           const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
           f16x8 o;
+          if constexpr (kAccSide) {
+            // the image already holds the finished fp16 values; the fp16 residual is one packed add per pair
+            // (the exact sum of two fp16 numbers, rounded once)
+            if constexpr (kResidH)
+              o = v + oldh[u];
+            else
+              o = v;
+          } else {
           float xs[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -357,6 +422,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)xs[e];
+          }
           const int64_t m = m0w + row;
           // non-temporal: the 128 KB a workgroup writes per tile would otherwise push the W panels out of the
           // XCD's L2 (W is re-fetched ~50x from the Infinity Cache per qkv launch); +1.4 % end to end
@@ -638,16 +704,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
   }
 
   int kc = 0, ti = 0;
-#ifdef HCIR_GEMM_STORE_DRAIN
-  bool landed = false;  // stage `step` was waited for before the previous tile's epilogue
-#endif
   for (int step = 0; step < nsteps; ++step) {
-#ifdef HCIR_GEMM_STORE_DRAIN
-    if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    landed = false;
-#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_s_barrier();
     HCIR_GSTAMP(ti == 1 && kc == 0, 0);
     HCIR_GSTAMP(ti == 2 && kc == 0, 4);
@@ -722,13 +780,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       int64_t m0;
       tile_origin(ti, n0, m0);
       HCIR_GSTAMP(ti == 1, 1);
-#ifdef HCIR_GEMM_STORE_DRAIN
-      // The next tile's first stage was issued early in this step: wait for it HERE, before the epilogue's stores
-      // join the same counter, so that the step behind the epilogue starts on a barrier alone and the store
-      // acknowledgements (1.3 - 4 us per tile when that step's vmcnt(0) waited for them) drain under its MFMAs.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      landed = step + 1 < nsteps;
-#endif
       // all waves are done reading slot step&1 (their MFMAs have consumed it) after this barrier;
       // the slot stays free until the DMA of stage step+2 is issued behind the next step's barrier
       __builtin_amdgcn_s_barrier();

@@ -157,8 +157,9 @@ typedef enum {
   HCIR_EPI_BIAS_F32 = 3,      /* out_f32 = acc + bias                                           */
   HCIR_EPI_AFFINE_RELU_F16 = 4,/* out_f16 = relu(acc * scale[n] + bias[n])  (proj-head Linear+BN+ReLU, eval) */
   HCIR_EPI_AFFINE_F32 = 5,    /* out_f32 = acc * scale[n] + bias[n]        (proj-head Linear+BN, eval)      */
-  HCIR_EPI_BIAS_RESID_F16 = 6 /* out_f16 += scale[n] * (acc + bias)        (fp16 residual stream; the add */
-                              /*   is done in fp32, one rounding to fp16)                              */
+  HCIR_EPI_BIAS_RESID_F16 = 6 /* out_f16 += scale[n] * (acc + bias)        (fp16 residual stream; the     */
+                              /*   product term is formed in fp32 and rounded to fp16, the sum of the  */
+                              /*   two fp16 numbers is rounded once)                                   */
 } hcir_epilogue;
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T).  A, W fp16 row-major (W is the

@@ -79,18 +79,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
                                                             int d, const float* __restrict__ dres_in,
                                                             float* __restrict__ dres_out, int64_t ldr,
                                                             float* __restrict__ dgamma_part,
-                                                            float* __restrict__ dbeta_part) {
+                                                            float* __restrict__ dbeta_part,
+                                                            _Float16* __restrict__ dres16, int64_t ldh,
+                                                            float* __restrict__ dres_part) {
   __shared__ float red[4][2];
-  extern __shared__ float colacc[];  // [2][d] per workgroup, combined across the 4 waves at the end
+  extern __shared__ float colacc[];  // [2 or 3][d] per workgroup, combined across the 4 waves at the end
   // NJ = column groups of 256 per row, a compile-time bound: with a run-time bound the per-lane arrays (4 x 16 x 4
   // floats) went to scratch and the kernel ran 5x off its HBM time
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int nj = NJ;
-  float gsum[NJ][4], bsum[NJ][4];
+  // optional third product (hcir_layernorm_bwd_fused): the fp16 copy of dres_out - the next dgrad / wgrad GEMM's
+  // operand - and the column sums of that copy - the bias gradient of the Linear layer in front
+  float gsum[NJ][4], bsum[NJ][4], rsum[NJ][4];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) gsum[j][e] = bsum[j][e] = 0.f;
+    for (int e = 0; e < 4; ++e) gsum[j][e] = bsum[j][e] = rsum[j][e] = 0.f;
   (void)red;
 
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
@@ -174,6 +178,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
             for (int e = 0; e < 4; ++e) o[e] += r0[e];
           }
           *reinterpret_cast<f32x4*>(dres_out + row * ldr + c) = o;
+          if (dres16) {
+            f16x4 oh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              oh[e] = (_Float16)o[e];
+              rsum[j][e] += (float)oh[e];
+            }
+            *reinterpret_cast<f16x4*>(dres16 + row * ldh + c) = oh;
+          }
         }
       }
     }
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
             for (int e = 0; e < 4; ++e) {
               colacc[c + e] = (w ? colacc[c + e] : 0.f) + gsum[j][e];
               colacc[d + c + e] = (w ? colacc[d + c + e] : 0.f) + bsum[j][e];
+              if (dres_part) colacc[2 * d + c + e] = (w ? colacc[2 * d + c + e] : 0.f) + rsum[j][e];
             }
           }
         }
@@ -200,6 +214,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
   for (int c = threadIdx.x; c < d; c += 256) {
     dgamma_part[(int64_t)blockIdx.x * d + c] = colacc[c];
     dbeta_part[(int64_t)blockIdx.x * d + c] = colacc[d + c];
+    if (dres_part) dres_part[(int64_t)blockIdx.x * d + c] = colacc[2 * d + c];
   }
 }
 
@@ -242,6 +257,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const _Float16* __restrict_
       const f16x8 v = *reinterpret_cast<const f16x8*>(x + r * ldx + c0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w][c];
+    part[(int64_t)blockIdx.y * n + blockIdx.x * 256 + c] = s;
+  }
+}
+
+// ---------------------------------------------------------------- GELU backward + the bias gradient's column sums
+// du = dh o gelu'(u) and part[chunk][c] = sum over the chunk's rows of the STORED fp16 du: colsum_kernel's geometry
+// and summation order with the elementwise pass inside (the bias gradient of fc1 costs no pass of its own, and it
+// is bit-identical to hcir_gelu_bwd_f16 followed by hcir_colsum_f16).
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const _Float16* __restrict__ u,
+                                                              const _Float16* __restrict__ dh, int64_t m, int n,
+                                                              int64_t ld, int64_t rows_per, _Float16* __restrict__ du,
+                                                              float* __restrict__ part) {
+  __shared__ float red[8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < m ? r0 + rows_per : m;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c0 < n) {
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(u + r * ld + c0);
+      const f16x8 g = *reinterpret_cast<const f16x8*>(dh + r * ld + c0);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (_Float16)((float)g[e] * gelu_erf_grad((float)v[e]));
+        acc[e] += (float)o[e];
+      }
+      *reinterpret_cast<f16x8*>(du + r * ld + c0) = o;
     }
   }
 #pragma unroll
@@ -389,21 +444,33 @@ int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int6
                        int64_t lddy, const float* gamma, float eps, const float* dres_in, float* dres_out,
                        int64_t ldr, float* dgamma, float* dbeta, int accumulate, float* workspace,
                        size_t workspace_bytes, void* stream) {
+  return hcir_layernorm_bwd_fused(x, x_dtype, rows, d, ldx, dy_f16, lddy, gamma, eps, dres_in, dres_out, ldr, dgamma,
+                                  dbeta, accumulate, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+int hcir_layernorm_bwd_fused(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx, const void* dy_f16,
+                             int64_t lddy, const float* gamma, float eps, const float* dres_in, float* dres_out,
+                             int64_t ldr, float* dgamma, float* dbeta, int accumulate, void* dres_f16, int64_t ldh,
+                             float* dres_colsum, float* workspace, size_t workspace_bytes, void* stream) {
   HCIR_ENTER();
   if (!x || !dy_f16 || !gamma || !dres_out || !dgamma || !dbeta || !workspace) return HCIR_ERR_INVALID;
   if (rows <= 0 || d <= 0 || (d & 3) || d > 4 * 64 * kLnMaxJ || ldx < d || lddy < d || ldr < d || (ldr & 3))
     return HCIR_ERR_INVALID;
+  if (dres_colsum && !dres_f16) return HCIR_ERR_INVALID;
+  if (dres_f16 && (ldh < d || (ldh & 3))) return HCIR_ERR_INVALID;
   if (x_dtype != HCIR_F32 && x_dtype != HCIR_F16) return HCIR_ERR_UNSUPPORTED;
   const int blocks = hcir_layernorm_bwd_blocks(rows);
-  if (workspace_bytes < (size_t)blocks * d * 2 * sizeof(float)) return HCIR_ERR_WORKSPACE;
+  const int narr = dres_colsum ? 3 : 2;
+  if (workspace_bytes < (size_t)blocks * d * narr * sizeof(float)) return HCIR_ERR_WORKSPACE;
   float* gpart = workspace;
   float* bpart = workspace + (size_t)blocks * d;
+  float* rpart = dres_colsum ? workspace + (size_t)2 * blocks * d : nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t shm = (size_t)2 * d * sizeof(float);
+  const size_t shm = (size_t)narr * d * sizeof(float);
 #define LNB(XT, NJV)                                                                                                \
   hipLaunchKernelGGL((layernorm_bwd_kernel<XT, NJV>), dim3(blocks), dim3(256), shm, st, static_cast<const XT*>(x), ldx, \
                      static_cast<const _Float16*>(dy_f16), lddy, gamma, eps, rows, d, dres_in, dres_out, ldr, gpart,  \
-                     bpart)
+                     bpart, static_cast<_Float16*>(dres_f16), ldh, rpart)
 #define LNB_NJ(XT)                       \
   do {                                   \
     if (nj <= 1) LNB(XT, 1);             \
@@ -424,6 +491,11 @@ int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int6
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 64), 2), dim3(256), 0, st, gpart, blocks, d,
                      dgamma, dbeta, accumulate);
   HCIR_LAUNCH_CHECK();
+  if (dres_colsum) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 64), 1), dim3(256), 0, st, rpart, blocks, d,
+                       dres_colsum, dres_colsum, 0);
+    HCIR_LAUNCH_CHECK();
+  }
   return HCIR_OK;
 }
 
@@ -445,6 +517,25 @@ int hcir_colsum_f16(const void* x, int64_t m, int32_t n, int64_t ldx, float* out
   HCIR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 64), 1), dim3(256), 0, st, workspace, chunks, n,
                      out, out, accumulate);
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+}
+
+int hcir_gelu_bwd_colsum_f16(const void* u, const void* dh, int64_t m, int32_t n, int64_t ld, void* du, float* colsum,
+                             int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  HCIR_ENTER();
+  if (!u || !dh || !du || !colsum || !workspace || m <= 0 || n <= 0 || (n & 7) || ld < n || (ld & 7))
+    return HCIR_ERR_INVALID;
+  const int chunks = hcir_colsum_chunks(m);
+  if (workspace_bytes < (size_t)chunks * n * sizeof(float)) return HCIR_ERR_WORKSPACE;
+  const int64_t rows_per = hcir_cdiv(m, chunks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)hcir_cdiv(n, 256), (unsigned)chunks), dim3(256), 0, st,
+                     static_cast<const _Float16*>(u), static_cast<const _Float16*>(dh), m, n, ld, rows_per,
+                     static_cast<_Float16*>(du), workspace);
+  HCIR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 64), 1), dim3(256), 0, st, workspace, chunks, n,
+                     colsum, colsum, accumulate);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

@@ -69,6 +69,9 @@ SIGNATURES = {
     "hcir_layernorm_bwd_blocks": (c_i32, [c_i64]),
     "hcir_layernorm_bwd": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_i64,
                                    c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "hcir_layernorm_bwd_fused": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp,
+                                         c_i64, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_gelu_bwd_colsum_f16": (c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_int, c_vp, c_sz, c_vp]),
     "hcir_colsum_chunks": (c_i32, [c_i64]),
     "hcir_colsum_f16": (c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_int, c_vp, c_sz, c_vp]),
     "hcir_gemm_f16_tn_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),

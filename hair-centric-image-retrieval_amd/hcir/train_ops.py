@@ -53,9 +53,11 @@ def add_to_f16(a: torch.Tensor, b: Optional[torch.Tensor] = None, out: Optional[
 def layernorm_bwd(x: torch.Tensor, dy16: torch.Tensor, gamma: torch.Tensor, eps: float,
                   dres_in: Optional[torch.Tensor], dres_out: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
                   accumulate: bool = True, rows: Optional[int] = None, ldx: Optional[int] = None,
-                  ldr: Optional[int] = None) -> None:
+                  ldr: Optional[int] = None, dres16: Optional[torch.Tensor] = None,
+                  dres_colsum: Optional[torch.Tensor] = None) -> None:
     """dres_out = dres_in + LayerNorm'(x)[dy16];  dgamma / dbeta (+)= the column reductions.
-    x [rows, d] (fp32 or fp16, row pitch ldx), dy16 fp16 [rows, d], dres_* fp32 (row pitch ldr)."""
+    x [rows, d] (fp32 or fp16, row pitch ldx), dy16 fp16 [rows, d], dres_* fp32 (row pitch ldr).
+    dres16 (fp16 [rows, d]): also receives fp16(dres_out); dres_colsum (fp32 [d]): the column sums of that copy."""
     for t, n in ((x, "x"), (dy16, "dy"), (gamma, "gamma"), (dres_out, "dres_out"), (dgamma, "dgamma"), (dbeta, "dbeta")):
         _dev(t, n)
     d = gamma.numel()
@@ -64,10 +66,31 @@ def layernorm_bwd(x: torch.Tensor, dy16: torch.Tensor, gamma: torch.Tensor, eps:
     ldr = d if ldr is None else ldr
     L = _lib.lib()
     nb = L.hcir_layernorm_bwd_blocks(rows)
-    ws = _ws.get(x.device, nb * d * 8)
-    check(L.hcir_layernorm_bwd(x.data_ptr(), _XDT[x.dtype], rows, d, ldx, dy16.data_ptr(), d, gamma.data_ptr(),
-                               float(eps), _p(dres_in), dres_out.data_ptr(), ldr, dgamma.data_ptr(), dbeta.data_ptr(),
-                               int(accumulate), ws.data_ptr(), ws.numel(), _stream(x)), "hcir_layernorm_bwd")
+    ws = _ws.get(x.device, nb * d * 12)
+    if dres16 is not None:
+        _dev(dres16, "dres16")
+        if dres16.dtype != torch.float16 or dres16.stride(0) != d:
+            raise HcirError("dres16: fp16 [rows, d], contiguous rows")
+    check(L.hcir_layernorm_bwd_fused(x.data_ptr(), _XDT[x.dtype], rows, d, ldx, dy16.data_ptr(), d, gamma.data_ptr(),
+                                     float(eps), _p(dres_in), dres_out.data_ptr(), ldr, dgamma.data_ptr(),
+                                     dbeta.data_ptr(), int(accumulate), _p(dres16), d, _p(dres_colsum), ws.data_ptr(),
+                                     ws.numel(), _stream(x)), "hcir_layernorm_bwd_fused")
+
+
+def gelu_bwd_colsum(u: torch.Tensor, dh: torch.Tensor, du: torch.Tensor, colsum_out: torch.Tensor,
+                    rows: Optional[int] = None, accumulate: bool = False) -> None:
+    """du = dh * gelu'(u) over the first `rows` rows of [m, n] fp16 matrices, and colsum_out[n] (+)= sum_rows du."""
+    for t, nm in ((u, "u"), (dh, "dh"), (du, "du"), (colsum_out, "colsum")):
+        _dev(t, nm)
+    if u.dtype != torch.float16 or dh.dtype != torch.float16 or du.dtype != torch.float16 or u.shape != dh.shape:
+        raise HcirError("gelu_bwd_colsum expects fp16 matrices of equal shape")
+    m = u.shape[0] if rows is None else rows
+    n = u.shape[1]
+    L = _lib.lib()
+    ws = _ws.get(u.device, L.hcir_colsum_chunks(m) * n * 4)
+    check(L.hcir_gelu_bwd_colsum_f16(u.data_ptr(), dh.data_ptr(), m, n, u.stride(0), du.data_ptr(),
+                                     colsum_out.data_ptr(), int(accumulate), ws.data_ptr(), ws.numel(), _stream(u)),
+          "hcir_gelu_bwd_colsum_f16")
 
 
 def colsum(x16: torch.Tensor, out: torch.Tensor, accumulate: bool = True, rows: Optional[int] = None) -> None:

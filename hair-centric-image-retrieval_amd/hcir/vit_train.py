@@ -41,13 +41,14 @@ def _pad64(m: int) -> int:
 
 class _Saved:
     """Activations of one training forward (device buffers; rows padded to a multiple of 64 with zeros)."""
-    __slots__ = ("b", "t", "m", "x_in", "qkv", "att", "lse", "x_mid", "u", "x_out", "patches")
+    __slots__ = ("b", "t", "m", "x_in", "qkv", "att", "lse", "x_mid", "u", "ln1", "ln2", "h", "x_out", "patches")
 
 
 class VitTrainer:
     """fp16 operand copies of a ViT's weights (as stored and transposed) + the training forward / backward."""
 
-    def __init__(self, spec: VitSpec, device: torch.device):
+    def __init__(self, spec: VitSpec, device: torch.device, keep_recomputable: bool = True):
+        self.keep_recomputable = bool(keep_recomputable)
         if device.type != "cuda":
             raise HcirError(f"VitTrainer needs a HIP device, got {device} (no CPU fallback)")
         if spec.dim % spec.heads or spec.dim // spec.heads != 64:
@@ -135,7 +136,7 @@ class VitTrainer:
 
         sv = _Saved()
         sv.b, sv.t, sv.m = b, t, m
-        sv.x_in, sv.qkv, sv.att, sv.lse, sv.x_mid, sv.u = ([] for _ in range(6))
+        sv.x_in, sv.qkv, sv.att, sv.lse, sv.x_mid, sv.u, sv.ln1, sv.ln2, sv.h = ([] for _ in range(9))
         # im2col of the patches in (c, ky, kx) order: the weight gradient of conv_proj needs it (data movement only)
         gh, gw = hh // ps, ww // ps
         pm = _pad64(b * gh * gw)
@@ -150,16 +151,28 @@ class VitTrainer:
                                  st), "hcir_patch_embed")
         scale = (d // self.heads) ** -0.5
         cur = tok
-        ln, h = z16(d), z16(self.mlp)          # not kept: recomputed in the backward
+        # The LayerNorm outputs and gelu(u) are KEPT as well (they are the A operands of the weight-gradient GEMMs):
+        # 3.6 KB more per token and layer - 65 GB for config C3's three 1024-image forwards, of 288 - instead of two
+        # LayerNorm and one GELU launch per layer in the backward (keep_recomputable=False restores the recompute).
+        keep = self.keep_recomputable
+        ln, h = (None, None) if keep else (z16(d), z16(self.mlp))
         for w in self.lw:
             qkv, att = z16(3 * d), z16(d)
             lse = torch.empty((b, self.heads, t), dtype=torch.float32, device=dev)
+            if keep:
+                ln = z16(d)
             self._ln(cur, m, d, d, w["ln1_w"], w["ln1_b"], ln, st)
+            if keep:
+                sv.ln1.append(ln)
             self._gemm(ln, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
             T.attn_fwd_lse(qkv, b, t, self.heads, scale, att, lse)
             x_mid = cur.clone()
             self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)")
             u = z16(self.mlp)
+            if keep:
+                ln, h = z16(d), z16(self.mlp)
+                sv.ln2.append(ln)
+                sv.h.append(h)
             self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln, st)
             self._gemm(ln, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
             check(L.hcir_gelu_fwd_f16(u.data_ptr(), m * self.mlp, h.data_ptr(), st), "hcir_gelu_fwd_f16")
@@ -190,14 +203,19 @@ class VitTrainer:
         T.layernorm_bwd(sv.x_out, dcls16, self.fln_w, self.eps, None, dres, g_flw, g_flb, accumulate=False, rows=b,
                         ldx=t * d, ldr=t * d)
         big16 = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)     # d_h / d_u
-        hbuf = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)      # gelu(u), recomputed per block
-        lnbuf = torch.zeros((mp, d), dtype=torch.float16, device=dev)            # LayerNorm output, recomputed
+        # gelu(u) / LayerNorm output: recomputed per block only when the forward did not keep them
+        hbuf = None if sv.h else torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)
+        lnbuf = None if sv.ln1 else torch.zeros((mp, d), dtype=torch.float16, device=dev)
         dqkv = torch.zeros((mp, 3 * d), dtype=torch.float16, device=dev)
         datt = torch.zeros((mp, d), dtype=torch.float16, device=dev)
         dln = torch.zeros((mp, d), dtype=torch.float16, device=dev)
         layer_grads = []
         scale = (d // self.heads) ** -0.5
         nelem = m * d
+        # dy16 = fp16(dres) and its column sums (the bias gradient of the Linear in front) come out of the LayerNorm
+        # backward that produced dres (hcir_layernorm_bwd_fused) - except for the last block, whose dres is the
+        # gradient of the final LayerNorm (class-token rows only)
+        fc2_b_next = None
         for li in range(len(self.lw) - 1, -1, -1):
             w = self.lw[li]
             g = {k: f32z(*shape) for k, shape in (
@@ -205,31 +223,43 @@ class VitTrainer:
                 ("proj_b", (d,)), ("ln2_w", (d,)), ("ln2_b", (d,)), ("fc1_w", (self.mlp, d)), ("fc1_b", (self.mlp,)),
                 ("fc2_w", (d, self.mlp)), ("fc2_b", (d,)))}
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-            check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
+            if fc2_b_next is None:
+                check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
+                T.colsum(dy16, g["fc2_b"], accumulate=False, rows=m)
+            else:
+                g["fc2_b"] = fc2_b_next
             self._gemm(dy16, d, w["fc2_wt"], None, m, self.mlp, _lib.EPI_BIAS_F16, big16, st, "dgrad(fc2)")
-            check(L.hcir_gelu_fwd_f16(sv.u[li].data_ptr(), m * self.mlp, hbuf.data_ptr(), st), "hcir_gelu_fwd_f16")
-            T.gemm_tn(dy16, hbuf, g["fc2_w"], accumulate=False)
-            T.colsum(dy16, g["fc2_b"], accumulate=False, rows=m)
-            check(L.hcir_gelu_bwd_f16(sv.u[li].data_ptr(), big16.data_ptr(), m * self.mlp, big16.data_ptr(), st),
-                  "hcir_gelu_bwd_f16")
+            if sv.h:
+                hcur = sv.h[li]
+            else:
+                hcur = hbuf
+                check(L.hcir_gelu_fwd_f16(sv.u[li].data_ptr(), m * self.mlp, hbuf.data_ptr(), st), "hcir_gelu_fwd_f16")
+            T.gemm_tn(dy16, hcur, g["fc2_w"], accumulate=False)
+            T.gelu_bwd_colsum(sv.u[li], big16, big16, g["fc1_b"], rows=m)     # d_u in place, + the fc1 bias gradient
             self._gemm(big16, self.mlp, w["fc1_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(fc1)")
-            self._ln(sv.x_mid[li], m, d, d, w["ln2_w"], w["ln2_b"], lnbuf, st)
-            T.gemm_tn(big16, lnbuf, g["fc1_w"], accumulate=False)
-            T.colsum(big16, g["fc1_b"], accumulate=False, rows=m)
+            if sv.ln2:
+                lncur = sv.ln2[li]
+            else:
+                lncur = lnbuf
+                self._ln(sv.x_mid[li], m, d, d, w["ln2_w"], w["ln2_b"], lnbuf, st)
+            T.gemm_tn(big16, lncur, g["fc1_w"], accumulate=False)
             T.layernorm_bwd(sv.x_mid[li], dln, w["ln2_w"], self.eps, dres, dres, g["ln2_w"], g["ln2_b"],
-                            accumulate=False, rows=m)
+                            accumulate=False, rows=m, dres16=dy16, dres_colsum=g["proj_b"])
             # ---- attention: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
-            check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")
             self._gemm(dy16, d, w["proj_wt"], None, m, d, _lib.EPI_BIAS_F16, datt, st, "dgrad(proj)")
             T.gemm_tn(dy16, sv.att[li], g["proj_w"], accumulate=False)
-            T.colsum(dy16, g["proj_b"], accumulate=False, rows=m)
             T.attn_bwd(sv.qkv[li], sv.att[li], datt, sv.lse[li], b, t, self.heads, scale, dqkv)
             self._gemm(dqkv, 3 * d, w["qkv_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(qkv)")
-            self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
-            T.gemm_tn(dqkv, lnbuf, g["qkv_w"], accumulate=False)
+            if sv.ln1:
+                lncur = sv.ln1[li]
+            else:
+                lncur = lnbuf
+                self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
+            T.gemm_tn(dqkv, lncur, g["qkv_w"], accumulate=False)
             T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
+            fc2_b_next = f32z(d) if li > 0 else None
             T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
-                            accumulate=False, rows=m)
+                            accumulate=False, rows=m, dres16=dy16 if li > 0 else None, dres_colsum=fc2_b_next)
             layer_grads.append(g)
         layer_grads.reverse()
         # ---- patch embedding: tok[b][0] = cls + pos_mult pos[0]; tok[b][1+p] = W patch + bias + pos_mult pos[1+p]

@@ -311,6 +311,11 @@ int hcir_retrieval_metrics(const int64_t* retrieved, int64_t nq, int32_t kmax, c
  * (MLPBlock / timm Mlp activation, HP/src/main_backbone.py:554; HP/src/models_vit.py:19). */
 int hcir_gelu_fwd_f16(const void* u, int64_t n, void* h, void* stream);
 int hcir_gelu_bwd_f16(const void* u, const void* dh, int64_t n, void* du, void* stream);
+/* The same backward over an [m, n] matrix (row pitch ld) that also leaves colsum[n] (+)= sum_m du[m][n] - the bias
+ * gradient of fc1 - in the same pass; bit-identical to hcir_gelu_bwd_f16 followed by hcir_colsum_f16.
+ * workspace: hcir_colsum_chunks(m) * n floats. */
+int hcir_gelu_bwd_colsum_f16(const void* u, const void* dh, int64_t m, int32_t n, int64_t ld, void* du, float* colsum,
+                             int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 
 /* y_f16 = fp16(a + b)  (b may be NULL): the fp32 residual gradient as the next GEMM's fp16 operand. n % 4 == 0 */
 int hcir_add_f32_f16(const float* a, const float* b, int64_t n, void* y, void* stream);
@@ -326,6 +331,14 @@ int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int6
                        int64_t lddy, const float* gamma, float eps, const float* dres_in, float* dres_out,
                        int64_t ldr, float* dgamma, float* dbeta, int accumulate, float* workspace,
                        size_t workspace_bytes, void* stream);
+/* hcir_layernorm_bwd that also writes dres_f16[row] = fp16(dres_out[row]) (row pitch ldh) - the operand of the next
+ * dgrad / wgrad GEMM, otherwise one hcir_add_f32_f16 pass - and, if dres_colsum != NULL, dres_colsum[c] = sum_rows of
+ * that fp16 copy - the bias gradient of the Linear layer whose output gradient it is, otherwise one hcir_colsum_f16
+ * pass.  dres_f16 NULL: exactly hcir_layernorm_bwd.  workspace: 3 * hcir_layernorm_bwd_blocks(rows) * d floats. */
+int hcir_layernorm_bwd_fused(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx, const void* dy_f16,
+                             int64_t lddy, const float* gamma, float eps, const float* dres_in, float* dres_out,
+                             int64_t ldr, float* dgamma, float* dbeta, int accumulate, void* dres_f16, int64_t ldh,
+                             float* dres_colsum, float* workspace, size_t workspace_bytes, void* stream);
 
 /* out[n] (+)= sum_m x[m][n] of an fp16 matrix: the bias gradient of a Linear layer.
  * workspace: hcir_colsum_chunks(m) * n floats. */

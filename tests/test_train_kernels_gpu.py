@@ -81,6 +81,49 @@ def test_layernorm_bwd_strided_cls_rows():
     assert float(dres[:, 1:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,d", [(197 * 5, 768), (3000, 768), (7, 128)])
+def test_layernorm_bwd_fused_copy_and_colsum(rows, d):
+    """hcir_layernorm_bwd_fused: same dres_out / dgamma / dbeta as hcir_layernorm_bwd (bit for bit), plus the fp16 copy
+    of dres_out (== hcir_add_f32_f16 of it, bit for bit) and that copy's column sums (vs float64)."""
+    from hcir import train_ops as T
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(rows, d, generator=g) * 1.5 + 0.3).half().cuda()
+    dy = torch.randn(rows, d, generator=g).half().cuda()
+    gamma = (1.0 + 0.2 * torch.randn(d, generator=g)).cuda()
+    dres = torch.randn(rows, d, generator=g).cuda()
+    o0, o1 = torch.empty(rows, d, device="cuda"), torch.empty(rows, d, device="cuda")
+    ga0, be0, ga1, be1 = (torch.zeros(d, device="cuda") for _ in range(4))
+    T.layernorm_bwd(x, dy, gamma, 1e-6, dres, o0, ga0, be0, accumulate=False)
+    h16 = torch.full((rows, d), 7.0, dtype=torch.float16, device="cuda")
+    cs = torch.full((d,), 3.0, device="cuda")
+    T.layernorm_bwd(x, dy, gamma, 1e-6, dres, o1, ga1, be1, accumulate=False, dres16=h16, dres_colsum=cs)
+    assert torch.equal(o0, o1) and torch.equal(ga0, ga1) and torch.equal(be0, be1)
+    assert torch.equal(h16, T.add_to_f16(o0))
+    assert (cs.cpu().double() - h16.cpu().double().sum(0)).abs().max() <= 1e-4 * np.sqrt(rows)
+    # the copy alone (no column sums)
+    h2 = torch.zeros_like(h16)
+    T.layernorm_bwd(x, dy, gamma, 1e-6, dres, o1, ga1, be1, accumulate=False, dres16=h2)
+    assert torch.equal(h2, h16)
+
+
+@pytest.mark.parametrize("m,n", [(1970, 3072), (50432, 3072), (13, 8)])
+def test_gelu_bwd_colsum_equals_the_two_kernels(m, n):
+    from hcir import train_ops as T
+    g = torch.Generator().manual_seed(12)
+    u = (torch.randn(m, n, generator=g) * 2.0).half().cuda()
+    dh = torch.randn(m, n, generator=g).half().cuda()
+    du_ref = T.gelu_bwd(u, dh)
+    cs_ref = torch.zeros(n, device="cuda")
+    T.colsum(du_ref, cs_ref, accumulate=False)
+    du = torch.empty_like(u)
+    cs = torch.full((n,), 5.0, device="cuda")
+    T.gelu_bwd_colsum(u, dh, du, cs)
+    assert torch.equal(du, du_ref) and torch.equal(cs, cs_ref)
+    dh2 = dh.clone()
+    T.gelu_bwd_colsum(u, dh2, dh2, cs, accumulate=True)            # in place, accumulating
+    assert torch.equal(dh2, du_ref) and torch.allclose(cs, 2 * cs_ref, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("m,n", [(50432, 768), (1000, 2304), (13, 8), (4096, 3072)])
 def test_colsum(m, n):
     from hcir import train_ops as T

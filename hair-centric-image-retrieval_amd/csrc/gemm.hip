@@ -42,6 +42,7 @@ struct GemmArgs {
   const float* ln_stats;  // [m][2] (mean, rstd) of the A rows           (EPI_LN_*)
   const float* ln_c1;     // [n]                                           (EPI_LN_*)
   float* stats_part;      // [n/64][m][2] partial (sum, sumsq) of out rows (EPI_RESID_F16_STATS)
+  const void* resid;      // residual rows of the *_RESID_* epilogues (same type and row pitch as out); == out: in place
 };
 
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8
@@ -92,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 
           *reinterpret_cast<f16x4*>(static_cast<_Float16*>(g.out) + m * g.ldo + n) = o;
         } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F16) {
           _Float16* p = static_cast<_Float16*>(g.out) + m * g.ldo + n;
-          const f16x4 oh = *reinterpret_cast<const f16x4*>(p);
+          const f16x4 oh = *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(g.resid) + m * g.ldo + n);
           f16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, const f32x16 
           *reinterpret_cast<f16x4*>(p) = o;
         } else if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
           float* p = static_cast<float*>(g.out) + m * g.ldo + n;
-          f32x4 o = *reinterpret_cast<const f32x4*>(p);
+          f32x4 o = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.resid) + m * g.ldo + n);
           if (g.scale) {
             const f32x4 s = *reinterpret_cast<const f32x4*>(g.scale + n);
 #pragma unroll
@@ -380,7 +381,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
 #pragma unroll
             for (int e = 0; e < 8; ++e) oldh[u][e] = (_Float16)0.f;
             if (FULL || mm < g.m)
-              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.out) + mm * g.ldo + n);
+              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.resid) + mm * g.ldo + n);
           }
         }
 #pragma unroll
@@ -468,7 +469,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           oldv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
             if (FULL || mm < g.m)
-              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.resid) + mm * g.ldo + n);
           }
         }
 #pragma unroll
@@ -927,7 +928,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) oldh[u][e] = (_Float16)0.f;
             if (FULL || mm < g.m)
-              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.out) + mm * g.ldo + n);
+              oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.resid) + mm * g.ldo + n);
           }
         }
 #pragma unroll
@@ -998,7 +999,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
           oldv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if constexpr (EPI == HCIR_EPI_BIAS_RESID_F32) {
             if (FULL || mm < g.m)
-              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) + mm * g.ldo + n);
+              oldv[u] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.resid) + mm * g.ldo + n);
           }
         }
 #pragma unroll
@@ -1413,7 +1414,14 @@ extern "C" {
 int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
                   const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, void* out,
                   int64_t ldo, void* stream) {
+  return hcir_gemm_f16_resid(a, lda, w, ldw, bias, scale, m, n, k, epilogue, nullptr, out, ldo, stream);
+}
+
+int hcir_gemm_f16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                        const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, const void* resid,
+                        void* out, int64_t ldo, void* stream) {
   HCIR_ENTER();
+  if (resid && epilogue != HCIR_EPI_BIAS_RESID_F16 && epilogue != HCIR_EPI_BIAS_RESID_F32) return HCIR_ERR_INVALID;
   if (!a || !w || !out || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
   if ((k & 7) || (n & 7) || lda < k || ldw < k || (lda & 7) || (ldw & 7) || ldo < n || (ldo & 3))
     return HCIR_ERR_INVALID;
@@ -1423,7 +1431,7 @@ int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw, const 
     return HCIR_ERR_INVALID;
   if (hcir_cdiv(m, 128) * hcir_cdiv(n, 128) > 0x7fffffff) return HCIR_ERR_INVALID;
   GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
-             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr};
+             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr, resid ? resid : out};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (epilogue) {
     case HCIR_EPI_BIAS_F16: launch_gemm<HCIR_EPI_BIAS_F16>(g, st); break;
@@ -1465,7 +1473,7 @@ int hcir_gemm_f16_fused(const void* a, int64_t lda, const void* w, int64_t ldw, 
   if (stats_part && epilogue != HCIR_EPI_BIAS_RESID_F16) return HCIR_ERR_UNSUPPORTED;
   if (!gemm_takes_big(m, n, k)) return HCIR_ERR_UNSUPPORTED;
   GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
-             lda, ldw, ldo, n, k, ln_stats, ln_c1, stats_part};
+             lda, ldw, ldo, n, k, ln_stats, ln_c1, stats_part, out};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stats_part) launch_gemm_big<EPI_RESID_F16_STATS>(g, st);
   else if (epilogue == HCIR_EPI_BIAS_F16) launch_gemm_big<EPI_LN_BIAS_F16>(g, st);

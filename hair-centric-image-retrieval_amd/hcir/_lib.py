@@ -48,6 +48,8 @@ SIGNATURES = {
     "hcir_layernorm_f16": (c_int, [c_vp, c_int, c_i64, c_i32, c_i64, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp]),
     "hcir_gemm_f16": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,
                               c_vp, c_i64, c_vp]),
+    "hcir_gemm_f16_resid": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int, c_vp,
+                                    c_vp, c_i64, c_vp]),
     "hcir_gemm_fused_supported": (c_int, [c_i64, c_i32, c_i32]),
     "hcir_gemm_stats_slices": (c_i32, [c_i32]),
     "hcir_gemm_f16_fused": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,

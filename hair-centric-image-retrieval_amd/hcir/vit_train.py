@@ -102,9 +102,9 @@ class VitTrainer:
         self._key = key
 
     # -- small helpers over the C ABI ---------------------------------------------------------------------------
-    def _gemm(self, a, k, w, bias, m, n, epi, out, st, what):
-        check(self.L.hcir_gemm_f16(a.data_ptr(), k, w.data_ptr(), k, _p(bias), None, m, n, k, epi, out.data_ptr(), n,
-                                   st), what)
+    def _gemm(self, a, k, w, bias, m, n, epi, out, st, what, resid=None):
+        check(self.L.hcir_gemm_f16_resid(a.data_ptr(), k, w.data_ptr(), k, _p(bias), None, m, n, k, epi, _p(resid),
+                                         out.data_ptr(), n, st), what)
 
     def _ln(self, x, rows, d, ldx, g, b, y, st):
         check(self.L.hcir_layernorm_f16(x.data_ptr(), _lib.F16, rows, d, ldx, g.data_ptr(), b.data_ptr(), self.eps,
@@ -166,8 +166,9 @@ class VitTrainer:
                 sv.ln1.append(ln)
             self._gemm(ln, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
             T.attn_fwd_lse(qkv, b, t, self.heads, scale, att, lse)
-            x_mid = cur.clone()
-            self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)")
+            x_mid = z16(d)       # out of place: `cur` is this block's saved input
+            self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)",
+                       resid=cur)
             u = z16(self.mlp)
             if keep:
                 ln, h = z16(d), z16(self.mlp)
@@ -176,9 +177,9 @@ class VitTrainer:
             self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln, st)
             self._gemm(ln, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
             check(L.hcir_gelu_fwd_f16(u.data_ptr(), m * self.mlp, h.data_ptr(), st), "hcir_gelu_fwd_f16")
-            x_out = x_mid.clone()
+            x_out = z16(d)
             self._gemm(h, self.mlp, w["fc2_w"], w["fc2_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_out, st,
-                       "hcir_gemm_f16(fc2)")
+                       "hcir_gemm_f16(fc2)", resid=x_mid)
             for lst, v in ((sv.x_in, cur), (sv.qkv, qkv), (sv.att, att), (sv.lse, lse), (sv.x_mid, x_mid), (sv.u, u)):
                 lst.append(v)
             cur = x_out

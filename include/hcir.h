@@ -172,6 +172,13 @@ typedef enum {
 int hcir_gemm_f16(const void* a, int64_t lda, const void* w, int64_t ldw,
                   const float* bias, const float* scale, int64_t m, int32_t n,
                   int32_t k, int epilogue, void* out, int64_t ldo, void* stream);
+/* The *_RESID_* epilogues out of place: out = resid + scale[n] * (acc + bias), resid [M, N] of out's type and row
+ * pitch (the residual add of a Block, x = x + attn(...) / x + mlp(...), HP/src/models_vit.py:147-149, when the
+ * block's input must survive - the training forward keeps it for the backward).  resid NULL or == out: in place,
+ * i.e. hcir_gemm_f16.  Any other epilogue with resid != NULL: HCIR_ERR_INVALID. */
+int hcir_gemm_f16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                        const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, const void* resid,
+                        void* out, int64_t ldo, void* stream);
 
 /* LayerNorm fused into the GEMMs on either side of it (persistent 256 x 256 kernel only:
  * hcir_gemm_fused_supported(m, n, k) != 0, i.e. M >= 1024, N % 256 == 0, K % 64 == 0).

@@ -96,6 +96,29 @@ def test_gemm_row_pitch(L, epi):
                            od.data_ptr(), ldo, _st()) == -1
 
 
+@pytest.mark.parametrize("m,n,k", [(1500, 512, 192), (300, 256, 128), (197 * 8, 768, 3072)])
+@pytest.mark.parametrize("epi", [2, 6])
+def test_gemm_residual_out_of_place(L, m, n, k, epi):
+    """hcir_gemm_f16_resid: out = resid + (acc + bias) with resid a separate buffer that stays untouched; bit-identical
+    to the in-place form on a copy (both the persistent and the small kernel); other epilogues refuse a resid."""
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    dt = torch.float32 if epi == 2 else torch.float16
+    a = (torch.randn(m, k, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).half().cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    resid = torch.randn(m, n, generator=g).to(dt).cuda()
+    keep = resid.clone()
+    out = torch.full((m, n), 9.0, dtype=dt, device="cuda")
+    assert L.hcir_gemm_f16_resid(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, epi,
+                                 resid.data_ptr(), out.data_ptr(), n, _st()) == 0
+    inplace = keep.clone()
+    assert L.hcir_gemm_f16(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, epi, inplace.data_ptr(), n,
+                           _st()) == 0
+    assert torch.equal(out, inplace) and torch.equal(resid, keep)
+    assert L.hcir_gemm_f16_resid(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, 0, resid.data_ptr(),
+                                 out.data_ptr(), n, _st()) == -1
+
+
 @pytest.mark.parametrize("m,d,mlp", [(1500, 256, 512), (197 * 6, 768, 3072)])
 def test_gemm_fused_layernorm(L, m, d, mlp):
     """hcir_gemm_f16_fused: (1) the fp16-residual epilogue also emits per-row (sum, sumsq) slices ->

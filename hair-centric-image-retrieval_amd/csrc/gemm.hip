@@ -30,6 +30,7 @@ using GemmCfg = SimCfg<_Float16, 2, 2, 2>;  // GM = 128 W rows, QB = 128 A rows
 constexpr int EPI_RESID_F16_STATS = 7;
 constexpr int EPI_LN_BIAS_F16 = 8;
 constexpr int EPI_LN_BIAS_GELU_F16 = 9;
+constexpr int EPI_BIAS_F16_DUAL_GELU = 10;  // out = fp16(acc + bias) AND out2 = fp16(gelu(acc + bias)) (hcir_gemm_f16_gelu_dual)
 
 struct GemmArgs {
   const _Float16* a;
@@ -43,6 +44,7 @@ struct GemmArgs {
   const float* ln_c1;     // [n]                                           (EPI_LN_*)
   float* stats_part;      // [n/64][m][2] partial (sum, sumsq) of out rows (EPI_RESID_F16_STATS)
   const void* resid;      // residual rows of the *_RESID_* epilogues (same type and row pitch as out); == out: in place
+  void* out2;             // second fp16 output of EPI_BIAS_F16_DUAL_GELU (row pitch ldo)
 };
 
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8
@@ -179,8 +181,10 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
   constexpr bool kLn = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_GELU_F16);
   constexpr bool kGelu = (EPI == HCIR_EPI_BIAS_GELU_F16 || EPI == EPI_LN_BIAS_GELU_F16);
   constexpr bool kResidH = (EPI == HCIR_EPI_BIAS_RESID_F16 || EPI == EPI_RESID_F16_STATS);
+  constexpr bool kDual = (EPI == EPI_BIAS_F16_DUAL_GELU);
+  static_assert(MF16 || !kDual, "the dual-output epilogue exists for the 16x16x32 accumulator layout only");
   constexpr bool kF16 = (EPI == HCIR_EPI_BIAS_F16 || kGelu || kLn ||
-                         EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH);
+                         EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH || kDual);
   constexpr bool kAffine = (EPI == HCIR_EPI_AFFINE_RELU_F16 || EPI == HCIR_EPI_AFFINE_F32);
   constexpr int NPASS = kF16 ? 2 : 4;  // 64 or 32 output features (128 B) per pass
   constexpr int NB = kF16 ? 2 : 1;     // float4 of bias per lane per pass
@@ -280,8 +284,13 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
       }
   }
 
+  // (dual output: every 64-feature pass runs twice through the same wave-private image - first the pre-activation,
+  // then its GELU; a wave's LDS operations execute in order, so the second write follows the first pass's reads)
+  constexpr int NITER = kDual ? 2 * NPASS : NPASS;
 #pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
+  for (int iter = 0; iter < NITER; ++iter) {
+    const int pass = kDual ? iter >> 1 : iter;
+    const bool second = kDual && (iter & 1);
     // ---- accumulators -> LDS (lane = output row m, registers = features n)
     if constexpr (!MF16) {
 #pragma unroll
@@ -344,7 +353,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
               }
               xs[e] = x;
             }
-            if constexpr (kGelu) {
+            if (kGelu || second) {
 #pragma unroll
               for (int e = 0; e < 4; e += 2) {
                 const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
@@ -428,7 +437,8 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
           // non-temporal: the 128 KB a workgroup writes per tile would otherwise push the W panels out of the
           // XCD's L2 (W is re-fetched ~50x from the Infinity Cache per qkv launch); +1.4 % end to end
           if (FULL || m < g.m)
-            __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n));
+            __builtin_nontemporal_store(
+                o, reinterpret_cast<f16x8*>(static_cast<_Float16*>(second ? g.out2 : g.out) + m * g.ldo + n));
           if constexpr (EPI == EPI_RESID_F16_STATS) {
             // (mean, sum of squared deviations from that mean) of the 64 STORED fp16 values of this row slice,
             // for the next LayerNorm.  Two-pass per slice (the values are in registers) and Chan's combination
@@ -1431,7 +1441,7 @@ int hcir_gemm_f16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, 
     return HCIR_ERR_INVALID;
   if (hcir_cdiv(m, 128) * hcir_cdiv(n, 128) > 0x7fffffff) return HCIR_ERR_INVALID;
   GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
-             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr, resid ? resid : out};
+             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr, resid ? resid : out, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (epilogue) {
     case HCIR_EPI_BIAS_F16: launch_gemm<HCIR_EPI_BIAS_F16>(g, st); break;
@@ -1445,6 +1455,23 @@ int hcir_gemm_f16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, 
   }
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
+}
+
+int hcir_gemm_f16_gelu_dual(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m,
+                            int32_t n, int32_t k, void* out_pre, void* out_act, int64_t ldo, void* stream) {
+  HCIR_ENTER();
+  if (!a || !w || !out_pre || !out_act || m <= 0 || n <= 0 || k <= 0) return HCIR_ERR_INVALID;
+  if (lda < k || ldw < k || (lda & 7) || (ldw & 7) || ldo < n || (ldo & 7)) return HCIR_ERR_INVALID;
+  if (!gemm_takes_big(m, n, k)) return HCIR_ERR_UNSUPPORTED;
+#if defined(HCIR_GEMM_MFMA32) || defined(HCIR_GEMM_MID)
+  return HCIR_ERR_UNSUPPORTED;
+#else
+  GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, nullptr, out_pre, m,
+             lda, ldw, ldo, n, k, nullptr, nullptr, nullptr, out_pre, out_act};
+  launch_gemm_big<EPI_BIAS_F16_DUAL_GELU>(g, static_cast<hipStream_t>(stream));
+  HCIR_LAUNCH_CHECK();
+  return HCIR_OK;
+#endif
 }
 
 #ifdef HCIR_DIAG_GSTAMPS
@@ -1473,7 +1500,7 @@ int hcir_gemm_f16_fused(const void* a, int64_t lda, const void* w, int64_t ldw, 
   if (stats_part && epilogue != HCIR_EPI_BIAS_RESID_F16) return HCIR_ERR_UNSUPPORTED;
   if (!gemm_takes_big(m, n, k)) return HCIR_ERR_UNSUPPORTED;
   GemmArgs g{static_cast<const _Float16*>(a), static_cast<const _Float16*>(w), bias, scale, out, m,
-             lda, ldw, ldo, n, k, ln_stats, ln_c1, stats_part, out};
+             lda, ldw, ldo, n, k, ln_stats, ln_c1, stats_part, out, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stats_part) launch_gemm_big<EPI_RESID_F16_STATS>(g, st);
   else if (epilogue == HCIR_EPI_BIAS_F16) launch_gemm_big<EPI_LN_BIAS_F16>(g, st);

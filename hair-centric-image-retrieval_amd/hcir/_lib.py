@@ -50,6 +50,7 @@ SIGNATURES = {
                               c_vp, c_i64, c_vp]),
     "hcir_gemm_f16_resid": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int, c_vp,
                                     c_vp, c_i64, c_vp]),
+    "hcir_gemm_f16_gelu_dual": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "hcir_gemm_fused_supported": (c_int, [c_i64, c_i32, c_i32]),
     "hcir_gemm_stats_slices": (c_i32, [c_i32]),
     "hcir_gemm_f16_fused": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_int,

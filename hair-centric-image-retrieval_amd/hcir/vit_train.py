@@ -175,8 +175,13 @@ class VitTrainer:
                 sv.ln2.append(ln)
                 sv.h.append(h)
             self._ln(x_mid, m, d, d, w["ln2_w"], w["ln2_b"], ln, st)
-            self._gemm(ln, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
-            check(L.hcir_gelu_fwd_f16(u.data_ptr(), m * self.mlp, h.data_ptr(), st), "hcir_gelu_fwd_f16")
+            if L.hcir_gemm_fused_supported(m, self.mlp, d):
+                # pre-activation (kept for the GELU backward) and activation from one pass over the accumulators
+                check(L.hcir_gemm_f16_gelu_dual(ln.data_ptr(), d, w["fc1_w"].data_ptr(), d, _p(w["fc1_b"]), m, self.mlp,
+                                                d, u.data_ptr(), h.data_ptr(), self.mlp, st), "hcir_gemm_f16_gelu_dual")
+            else:
+                self._gemm(ln, d, w["fc1_w"], w["fc1_b"], m, self.mlp, _lib.EPI_BIAS_F16, u, st, "hcir_gemm_f16(fc1)")
+                check(L.hcir_gelu_fwd_f16(u.data_ptr(), m * self.mlp, h.data_ptr(), st), "hcir_gelu_fwd_f16")
             x_out = z16(d)
             self._gemm(h, self.mlp, w["fc2_w"], w["fc2_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_out, st,
                        "hcir_gemm_f16(fc2)", resid=x_mid)

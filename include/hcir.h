@@ -180,6 +180,14 @@ int hcir_gemm_f16_resid(const void* a, int64_t lda, const void* w, int64_t ldw, 
                         const float* scale, int64_t m, int32_t n, int32_t k, int epilogue, const void* resid,
                         void* out, int64_t ldo, void* stream);
 
+/* fc1 of the TRAINING forward: out_pre = fp16(acc + bias) (the pre-activation the GELU backward needs) and
+ * out_act = fp16(gelu(acc + bias)) (the next GEMM's operand) from one pass over the accumulators - the value is
+ * formed once in fp32 and rounded twice - instead of a GEMM plus an hcir_gelu_fwd_f16 pass over M x N.
+ * (MLPBlock / timm Mlp fc1 + act, HP/src/main_backbone.py:554; HP/src/models_vit.py:19.)  Both outputs fp16 with row
+ * pitch ldo.  Persistent kernel only: HCIR_ERR_UNSUPPORTED unless hcir_gemm_fused_supported(m, n, k). */
+int hcir_gemm_f16_gelu_dual(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, int64_t m,
+                            int32_t n, int32_t k, void* out_pre, void* out_act, int64_t ldo, void* stream);
+
 /* LayerNorm fused into the GEMMs on either side of it (persistent 256 x 256 kernel only:
  * hcir_gemm_fused_supported(m, n, k) != 0, i.e. M >= 1024, N % 256 == 0, K % 64 == 0).
  * Replaces the  x -> norm1/ln_1 -> qkv   and   x -> norm2/ln_2 -> fc1   pairs of a Block

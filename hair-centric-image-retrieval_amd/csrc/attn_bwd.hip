@@ -4,8 +4,11 @@
 // torchvision's EncoderBlock (HP/src/main_backbone.py:554) in the training step (HP/src/pretrain_engine.py:745):
 //   P = softmax(scale q k^T)   dV = P^T dO   dP = dO V^T   dS = P o (dP - D),  D_q = sum_d dO[q][d] O[q][d]
 //   dQ = scale dS K            dK = scale dS^T Q
-// One 4-wave workgroup per (batch, head); wave w owns keys [64 w, 64 w + 64) (T <= 256) and keeps dK^T and dV^T of
-// its keys in registers for the whole sweep over the query tiles (cdna_hip_programming.md Appendix B, "Attention
+// One workgroup per (batch, head) of 8 / KT waves; wave w owns keys [32 KT w, 32 KT (w + 1)) (T <= 256) and keeps dK^T
+// and dV^T of its keys in registers for the whole sweep over the query tiles.  KT = 1 (eight waves of one 32-key tile,
+// two per SIMD) is what runs: with four waves of two tiles (the first version: ~350 registers, one wave per SIMD)
+// every LDS round trip and exp2 chain of the per-tile sequence stood exposed and the fourth wave owned 5 real keys of
+// 64 at T = 197 - 1.56 ms per launch at batch 1024 against the forward's 0.31 (cdna_hip_programming.md Appendix B, "Attention
 // backward": the KEY sits on the MFMA lane):
 //   S  = Q . K^T  and  dP = dO . V^T   MFMA 32x32x16, query on the row, key on the column: the accumulators
 //                                      ARE the B operands (contraction over their row index = the query) of
@@ -13,12 +16,12 @@
 //                                      ds_read_b64_tr_b16, in the permuted k order of an accumulator operand
 //                                      (cdna_hip_programming.md §3);
 //   dQ^T = K^T . dS^T                  contracts over the key = the lane index: dS crosses LDS once ([q][key] image,
-//                                      private to the wave), the per-wave partial dQ tiles (its 64 keys) meet in
-//                                      padded fp32 LDS slabs, summed in wave order, and leave as whole fp16 rows.
+//                                      private to the wave), the per-wave partial dQ tiles (its keys) meet in four
+//                                      padded fp32 LDS slabs (KT = 1: wave 2j writes slab j, wave 2j+1 adds to it),
+//                                      summed in slab order, and leave as whole fp16 rows: deterministic.
 // P is recomputed from the forward's per-row log2-sum-exp (hcir_attn_fwd_lse); D from dO and O at kernel start.
-// LDS: Q, dO, K images (3 x 32 KB), dS staging 4 x 4 KB, dQ slabs 4 x 8.3 KB, row constants 2 KB: 1 workgroup per CU,
-// one wave per SIMD (the kernel uses ~350 registers).  Correctness-first layouts: the images carry the row-read
-// swizzle only; transposed reads see some bank conflicts (the kernel is ~2 % of a training step).
+// LDS: Q, dO, K images (3 x 32 KB), dS staging 16 KB, dQ slabs 4 x 8.3 KB, row constants 2 KB: 1 workgroup per CU.
+// The images carry the row-read swizzle only; transposed reads see some bank conflicts.
 #include "common.h"
 
 namespace {
@@ -41,12 +44,19 @@ __device__ __forceinline__ int img_off(int row, int c16) { return row * 128 + ((
 // byte address of element column e0 (a multiple of 4) of `row`: a transposed read's 8-byte piece
 __device__ __forceinline__ int img_off_e(int row, int e0) { return img_off(row, e0 >> 3) + (e0 & 7) * 2; }
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
+template <int KT>
+__global__ __launch_bounds__(64 * (8 / KT), 1) void attn_bwd_kernel(AttnBwdArgs a) {
+  constexpr int NW = 8 / KT;        // waves
+  constexpr int NT = 64 * NW;       // threads
+  constexpr int KW = 32 * KT;       // keys per wave
+  constexpr int DSROW = 64 * KT;    // bytes per row of a wave's dS image (KW fp16)
+  constexpr int DSMASK = 4 * KT - 1;
+  auto ds_off = [](int row, int c16) { return row * DSROW + ((c16 ^ ((row >> 1) & DSMASK)) << 4); };
   __shared__ __attribute__((aligned(16))) char lds[3 * kTP * 128 + 4 * 4096 + 4 * 32 * 65 * 4 + 2 * kTP * 4];
   char* qs = lds;
   char* dos = lds + kTP * 128;
   char* ks = lds + 2 * kTP * 128;
-  char* dss = lds + 3 * kTP * 128;                                  // [4 waves][32 q][128 B]
+  char* dss = lds + 3 * kTP * 128;                                  // [NW waves][32 q][DSROW B]: 16 KB
   float* dqt = reinterpret_cast<float*>(lds + 3 * kTP * 128 + 4 * 4096);  // [4 waves][32][65]
   float* dsum = dqt + 4 * 32 * 65;                                  // D[q]
   float* lrow = dsum + kTP;                                         // lse[q]
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
   _Float16* dvg = dqg + (int64_t)2 * a.h * 64;
 
   // ---- stage Q, dO, K images (rows past T: Q, K clamped to the last real row - finite, masked below; dO zero)
-  for (int slot = tid; slot < kTP * 8; slot += 256) {
+  for (int slot = tid; slot < kTP * 8; slot += NT) {
     const int row = slot >> 3, c = slot & 7;
     const int src = row < a.t ? row : a.t - 1;
     const u32x4 qv = *reinterpret_cast<const u32x4*>(qg + src * qkv_stride + c * 8);
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
     *reinterpret_cast<u32x4*>(dos + img_off(row, c)) = dv;
   }
   // ---- row constants: D[q] = <dO[q], O[q]>, lse[q] (+inf past T: P = 0 there)
-  {
+  if (tid < kTP) {
     const int q = tid;
     float dsv = 0.f, lv = __builtin_huge_valf();
     if (q < a.t) {
@@ -96,10 +106,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
     lrow[q] = lv;
   }
   // ---- this wave's K and V fragments (B operands: lane (key = 64 w + 32 kt + r, half h) holds [key][16 s + 8 h ..])
-  f16x8 kf[2][4], vf[2][4];
+  f16x8 kf[KT][4], vf[KT][4];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    int key = 64 * wave + 32 * kt + r;
+  for (int kt = 0; kt < KT; ++kt) {
+    int key = KW * wave + 32 * kt + r;
     key = key < a.t ? key : a.t - 1;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -107,16 +117,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
       vf[kt][s] = *reinterpret_cast<const f16x8*>(vg + key * qkv_stride + 16 * s + 8 * h);
     }
   }
-  f32x16 dkt[2][2], dvt[2][2];  // [dim tile][key tile]: lane = key column, registers = dims
+  f32x16 dkt[2][KT], dvt[2][KT];  // [dim tile][key tile]: lane = key column, registers = dims
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+    for (int y = 0; y < KT; ++y)
 #pragma unroll
       for (int i = 0; i < 16; ++i) dkt[x][y][i] = dvt[x][y][i] = 0.f;
   __syncthreads();
 
-  char* myds = dss + wave * 4096;
+  char* myds = dss + wave * (32 * DSROW);
   const int nqt = (a.t + 31) >> 5;
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 32;
@@ -127,9 +137,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
       qf[s] = *reinterpret_cast<const f16x8*>(qs + img_off(q0 + r, 2 * s + h));
       dof[s] = *reinterpret_cast<const f16x8*>(dos + img_off(q0 + r, 2 * s + h));
     }
-    f32x16 sc[2], dp[2];
+    f32x16 sc[KT], dp[KT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sc[kt][i] = dp[kt][i] = 0.f;
 #pragma unroll
@@ -145,10 +155,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
       lq[i] = lrow[q0 + acc_row(i, h)];
       dq_[i] = dsum[q0 + acc_row(i, h)];
     }
-    f16x8 pf[2][2], dsf[2][2];  // [key tile][16-query k-step]
+    f16x8 pf[KT][2], dsf[KT][2];  // [key tile][16-query k-step]
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const bool live = 64 * wave + 32 * kt + r < a.t;
+    for (int kt = 0; kt < KT; ++kt) {
+      const bool live = KW * wave + 32 * kt + r < a.t;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], a.scale_log2e, -lq[i]));
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
         dsf[kt][i >> 3][i & 7] = (_Float16)dsv;
         // dS to the wave's [q][key] image for the dQ product (2-byte stores: 32 lanes = 64 contiguous bytes)
         const int qrow = acc_row(i, h), kcol = 32 * kt + r;
-        *reinterpret_cast<_Float16*>(myds + img_off(qrow, kcol >> 3) + (kcol & 7) * 2) = (_Float16)dsv;
+        *reinterpret_cast<_Float16*>(myds + ds_off(qrow, kcol >> 3) + (kcol & 7) * 2) = (_Float16)dsv;
       }
     }
     asm volatile("" ::: "memory");  // the 2-byte dS stores above are read back below through another pointer type
@@ -185,26 +195,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
           }
         }
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
           dvt[dt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf[kt][s], dvt[dt][kt], 0, 0, 0);
           dkt[dt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf[kt][s], dkt[dt][kt], 0, 0, 0);
         }
       }
     }
-    // ---- dQ^T[dim][q] = sum over this wave's 64 keys of K^T[dim][key] dS^T[key][q]
+    // ---- dQ^T[dim][q] = sum over this wave's keys of K^T[dim][key] dS^T[key][q]
     f32x16 dqa[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) dqa[dt][i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 2 * KT; ++s) {
       // B operand: lane (q = r, half h) holds dS[q][16 s + 8 h .. + 7] of the wave's image (natural k order)
-      const f16x8 dsb = *reinterpret_cast<const f16x8*>(myds + img_off(r, 2 * s + h));
+      const f16x8 dsb = *reinterpret_cast<const f16x8*>(myds + ds_off(r, 2 * s + h));
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const int c0 = 32 * dt + 16 * (grp & 1) + 4 * (li & 3);
-        const int kb = 64 * wave + 16 * s + 8 * (grp >> 1) + (li >> 2);
+        const int kb = KW * wave + 16 * s + 8 * (grp >> 1) + (li >> 2);
         f16x8 ktf;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -216,15 +226,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
         dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf, dsb, dqa[dt], 0, 0, 0);
       }
     }
-    // the four waves' partial tiles (their 64 keys each) go to per-wave LDS slabs (row pitch 65 floats: the 32
-    // queries of a register spread over the banks) and are summed in wave order: deterministic, no LDS atomics
-    // (an atomic version changed low bits from run to run, which fp16 roundings downstream amplified to 1e-4)
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dqt[wave * (32 * 65) + r * 65 + 32 * dt + acc_row(i, h)] = dqa[dt][i];
-    __syncthreads();
+    // the waves' partial tiles (their keys) go to four LDS slabs (row pitch 65 floats: the 32 queries of a register
+    // spread over the banks) and are summed in slab order: deterministic, no LDS atomics (an atomic version changed
+    // low bits from run to run, which fp16 roundings downstream amplified to 1e-4).  KT = 1: wave 2j stores slab j,
+    // then wave 2j+1 adds its tile to it.
     {
+      float* slab = dqt + (wave / (NW / 4)) * (32 * 65);
+      if (wave % (NW / 4) == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) slab[r * 65 + 32 * dt + acc_row(i, h)] = dqa[dt][i];
+      }
+      __syncthreads();
+      if constexpr (NW > 4) {
+        if (wave % (NW / 4) == 1) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) slab[r * 65 + 32 * dt + acc_row(i, h)] += dqa[dt][i];
+        }
+        __syncthreads();
+      }
+    }
+    if (tid < 256) {
       const int q = tid >> 3, c = tid & 7;
       f16x8 o;
 #pragma unroll
@@ -241,8 +266,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(AttnBwdArgs a) {
 
   // ---- dK = scale dK^T, dV = dV^T: lane = key, registers = dims in groups of 4
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    const int key = 64 * wave + 32 * kt + r;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int key = KW * wave + 32 * kt + r;
     if (key < a.t) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -274,7 +299,11 @@ extern "C" int hcir_attn_bwd(const void* qkv, const void* out, const void* d_out
   AttnBwdArgs a{static_cast<const _Float16*>(qkv), static_cast<const _Float16*>(out),
                 static_cast<const _Float16*>(d_out), lse, static_cast<_Float16*>(d_qkv), t, h, scale,
                 scale * 1.44269504088896340736f};
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(b * h)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+#ifdef HCIR_ATTN_BWD_KT2   // build flag: the first version (four waves of two key tiles), for A/B runs
+  hipLaunchKernelGGL(attn_bwd_kernel<2>, dim3((unsigned)(b * h)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+#else
+  hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3((unsigned)(b * h)), dim3(512), 0, static_cast<hipStream_t>(stream), a);
+#endif
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

@@ -9,7 +9,7 @@ b, t, h = (int(sys.argv[1]) if len(sys.argv) > 1 else 220), 197, 12
 qkv = (torch.randn(b, t, 3, h, 64, device="cuda")).half()
 out = torch.empty(b, t, h * 64, device="cuda", dtype=torch.float16)
 st = torch.cuda.current_stream().cuda_stream
-f = lambda: L.hcir_attn_fwd(qkv.data_ptr(), b, t, h, 64, 0.125, out.data_ptr(), st)
+f = lambda: L.hcir_attn_fwd(qkv.data_ptr(), b, t, h, 64, 0.125, t, out.data_ptr(), st)
 for _ in range(3): assert f() == 0
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

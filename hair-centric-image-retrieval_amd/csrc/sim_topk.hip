@@ -160,8 +160,12 @@ struct ScanArgs {
 // workgroups per CU (measured: the 64-query main scan 260 -> 780 us) and at one workgroup per CU they lose what the
 // batch gains (64-query call 333 -> 340 us); running a 64-query prefix as two 32-query blocks of this kernel was a
 // wash (prefix 52 -> 49 us).  The streaming launches behind a floor keep the lean kernel.
+// (KP = 16, one query tile x two wave columns, two row groups: 24 KB stages -> THREE workgroups per CU; the 64-query
+// geometry of the streaming launches, see make_plan)
 template <typename T, int KP, int QT, int WQ, int WGG, bool GLDS, bool CAND = false, bool BATCH = false>
-__global__ __launch_bounds__(256, ((KP <= 32 && GLDS) ? 2 : 1)) void sim_topk_scan(ScanArgs a) {
+__global__ __launch_bounds__(256, ((KP == 16 && QT == 1 && WQ == 2 && WGG == 2 && GLDS && !BATCH)
+                                       ? 3
+                                       : ((KP <= 32 && GLDS) ? 2 : 1))) void sim_topk_scan(ScanArgs a) {
   using Cfg = SimCfg<T, WGG, WQ, QT>;
   constexpr int EPS = SimElem<T>::kPerStage;
   constexpr int NSRC = 2 * WGG;  // lists per query inside a workgroup
@@ -981,6 +985,124 @@ __global__ __launch_bounds__(256) void topk_merge32_kernel(MergeArgs<int> a) {
 }
 
 // --------------------------------------------------------------------------
+// merge32q: merge32 with FOUR waves per query (kout <= 16).  The one-wave merge is a serial chain: every one of
+// the k rounds walks all LPL cached list heads of a lane (9 - 13 compare-select steps) before the wave maximum -
+// 17 - 26 us per launch for 512 - 768 lists, whatever the number of queries (<= 128 of them keep 16 - 32 CUs busy).
+// Here wave w of the workgroup takes lists w, w + 4, ... (a quarter of the heads per lane), the four 16-entry
+// results meet in LDS as 64 keys, and wave 0 ranks them by counting (lane i compares its key with the other 63):
+// rank r < kout stores output r.  Keys are all distinct (row indices are unique), so ranks are a permutation.
+// --------------------------------------------------------------------------
+template <int LPL>
+__global__ __launch_bounds__(256) void topk_merge32q_kernel(MergeArgs<int> a) {
+  __shared__ uint64_t part[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = blockIdx.x;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  if (a.zero_cnt && threadIdx.x == 0) {
+    a.zero_cnt[qi] = 0;
+    if (qi == 0) a.zero_cnt[a.nq] = 0;
+  }
+  const bool has_extra = a.extra_val != nullptr;
+  int nl = a.nlists;
+  if (a.nlists_q) nl = a.nlists_q[qi] < nl ? a.nlists_q[qi] : nl;
+  const int extra_list = nl;
+
+  auto fetch4 = [&](int list, int pos, uint64_t (&k4)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k4[e] = 0ull;
+    const float* pv = nullptr;
+    const int* pi = nullptr;
+    int len = 0;
+    if (list < nl) {
+      pv = a.vals + ((int64_t)list * a.nq + qi) * a.kin;
+      pi = a.idx + ((int64_t)list * a.nq + qi) * a.kin;
+      len = a.kin;
+    } else if (has_extra && list == extra_list) {
+      pv = a.extra_val + qi * a.kin_extra;
+      pi = a.extra_idx + qi * a.kin_extra;
+      len = a.kin_extra;
+    }
+    if (pos + 4 <= len && (len & 3) == 0) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pv + pos);
+      const u32x4 id = *reinterpret_cast<const u32x4*>(pi + pos);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) k4[e] = merge_key(v[e], (int)id[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pos + e < len) k4[e] = merge_key(pv[pos + e], pi[pos + e]);
+    }
+  };
+  // list of (wave, lane, j): wave + 4 (lane + 64 j)
+  uint64_t kq[LPL][4];
+  int used[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; ++j) {
+    used[j] = 0;
+    fetch4(wave + 4 * (lane + 64 * j), 0, kq[j]);
+  }
+  uint64_t mine = 0ull;
+  for (int o = 0; o < a.kout; ++o) {
+    uint64_t best = kq[0][0];
+    int bj = 0;
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) {
+      const bool take = kq[j][0] > best;
+      best = take ? kq[j][0] : best;
+      bj = take ? j : bj;
+    }
+    const uint64_t wm = wave_max_u64(best);
+    mine = (lane == o) ? wm : mine;
+    if (wm != 0ull && best == wm) {
+#pragma unroll
+      for (int j = 0; j < LPL; ++j) {
+        if (j == bj) {
+          kq[j][0] = kq[j][1];
+          kq[j][1] = kq[j][2];
+          kq[j][2] = kq[j][3];
+          kq[j][3] = 0ull;
+          used[j] += 1;
+          if ((used[j] & 3) == 0) fetch4(wave + 4 * (lane + 64 * j), used[j], kq[j]);
+        }
+      }
+    }
+  }
+  if (lane < 16) part[wave][lane] = lane < a.kout ? mine : 0ull;
+  __syncthreads();
+  if (wave != 0) return;
+  const uint64_t key = part[lane >> 4][lane & 15];
+  int rank = 0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, i);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), i);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    rank += o > key ? 1 : 0;
+  }
+  const int nnz = __builtin_popcountll(__ballot(key != 0ull));
+  if (key != 0ull && rank < a.kout) {
+    const float wv = merge_key_val(key);
+    const int wi = merge_key_idx(key);
+    a.out_val[qi * a.kout + rank] = wv;
+    if (a.out_idx) a.out_idx[qi * a.kout + rank] = (int64_t)wi + a.idx_base;
+    if (a.out_idx32) a.out_idx32[qi * a.kout + rank] = wi;
+    if (rank == a.kout - 1) {
+      if (a.kth_val) a.kth_val[qi] = wv;
+      if (a.kth_idx) a.kth_idx[qi] = wi;
+    }
+  }
+  if (lane >= nnz && lane < a.kout) {   // fewer than kout entries in all lists together
+    a.out_val[qi * a.kout + lane] = kNegInf;
+    if (a.out_idx) a.out_idx[qi * a.kout + lane] = -1;
+    if (a.out_idx32) a.out_idx32[qi * a.kout + lane] = -1;
+    if (lane == a.kout - 1) {
+      if (a.kth_val) a.kth_val[qi] = kNegInf;
+      if (a.kth_idx) a.kth_idx[qi] = -1;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // select: top-k of an UNSORTED candidate buffer (what the candidate-append scans leave: [cap][nq], cnt[nq]) plus an
 // optional sorted list per query (the prefix result).  One wave per query, every entry a 64-bit (score, ~row) key
 // in a register (lane l owns candidates l, l + 64, ...; its last slot takes entry l of the sorted list).
@@ -1277,14 +1399,27 @@ struct Plan {
 };
 
 constexpr int kMaxGridX = 512;  // 2 workgroups per CU; also <= 576 lists per merge pass
+// 33..64 queries with k <= 16 run as <one query tile x two wave columns> workgroups on 128-row tiles: 24 KB stages,
+// THREE workgroups per CU for the streaming launches (768 workgroups; the floorless launches get the batch-insertion
+// kernel of the one-query-tile geometry, two per CU) instead of two <two query tiles> workgroups with 40 KB stages.
+// Same-box A/B, 1 M x 768 fp16, 64 queries (tools/ab_sim.py): 318 -> 307 us (the prefix launch 52 -> 38 us; the main
+// scan unchanged at 5.7 TB/s).  -DHCIR_SCAN_Q64_TWO_TILES builds the earlier geometry.
+#ifndef HCIR_SCAN_Q64_TWO_TILES
+constexpr bool kQ64ThreePerCU = true;
+constexpr int kMaxGridQ64 = 768;
+#else
+constexpr bool kQ64ThreePerCU = false;
+constexpr int kMaxGridQ64 = kMaxGridX;
+#endif
+constexpr int kMaxParts = kMaxGridQ64 > kMaxGridX ? kMaxGridQ64 : kMaxGridX;
 
 // Workgroups along the gallery for `qblocks` query blocks.  Every query block scans every gallery tile; the
 // grid is sized so that ALL (tile run, query block) workgroups are resident at once (512 slots) and the blocks
 // of one tile run sit on the same XCD (linear id = x + grid_x * y, grid_x a multiple of 8): they stream the
 // same tiles in step and all but the first read them from that XCD's L2.  (With 512 workgroups per query
 // block the blocks ran one after the other and the gallery came from HBM once per block.)
-inline int scan_grid_x(int64_t tiles, int64_t qblocks) {
-  int64_t cap = kMaxGridX / (qblocks < 1 ? 1 : qblocks);
+inline int scan_grid_x(int64_t tiles, int64_t qblocks, int max_wg = kMaxGridX) {
+  int64_t cap = max_wg / (qblocks < 1 ? 1 : qblocks);
   cap = cap < 8 ? 8 : (cap & ~int64_t(7));
   return (int)(tiles < cap ? tiles : cap);
 }
@@ -1301,6 +1436,7 @@ Plan make_plan(int64_t nq, int64_t ng, int k) {
     p.qb = nq <= 32 ? 32 : (nq <= 64 ? 64 : 128);
   }
   p.gm = p.qb == 128 ? 128 : 256;
+  if (kQ64ThreePerCU && p.kp == 16 && p.qb == 64) p.gm = 128;   // <QT 1, WQ 2, WGG 2>: 128-row tiles, 3 workgroups per CU
   const int64_t tiles = hcir_cdiv(ng, p.gm);
   p.grid_main = (int)(tiles < kMaxGridX ? tiles : kMaxGridX);
   // prefix: ~1/16 of the gallery, at least 64 rows per list-k, in whole tiles
@@ -1328,6 +1464,30 @@ constexpr int kSelLPLBig = 48;
 constexpr int kCandCapBig = 64 * kSelLPLBig - 64;  // 3008
 constexpr int kMaxFloorGroups = 4;
 
+// the merge of up to `nlists` (+ the extra) sorted 32-bit-index lists: four waves per query for kout <= 16 with one
+// group, the one-wave kernel otherwise
+inline void launch_merge32(const MergeArgs<int>& m, hipStream_t st) {
+  const int total = m.nlists + (m.extra_val ? 1 : 0);
+  const int merge_grid = (int)hcir_cdiv(m.nq, 4);
+  if (m.kout <= 16 && m.ngroups <= 1 && total <= 256 * 4) {
+    const int lpl = (total + 255) / 256;
+    if (lpl <= 1)
+      hipLaunchKernelGGL(topk_merge32q_kernel<1>, dim3((unsigned)m.nq), dim3(256), 0, st, m);
+    else if (lpl == 2)
+      hipLaunchKernelGGL(topk_merge32q_kernel<2>, dim3((unsigned)m.nq), dim3(256), 0, st, m);
+    else if (lpl == 3)
+      hipLaunchKernelGGL(topk_merge32q_kernel<3>, dim3((unsigned)m.nq), dim3(256), 0, st, m);
+    else
+      hipLaunchKernelGGL(topk_merge32q_kernel<4>, dim3((unsigned)m.nq), dim3(256), 0, st, m);
+    return;
+  }
+  if (total > 64 * kMergeLPL)   // (callers keep their list counts within 64 * kCandLPL)
+    hipLaunchKernelGGL(topk_merge32_kernel<kCandLPL>, dim3(merge_grid), dim3(256), 0, st, m);
+  else
+    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
+}
+
+
 struct Workspace {
   float* part_val;
   int* part_idx;
@@ -1351,7 +1511,7 @@ Workspace carve(void* base, int64_t nq, int k, const Plan& p) {
     off += (n + 255) & ~size_t(255);
     return r;
   };
-  const size_t part = (size_t)kMaxGridX * nq * p.kp;
+  const size_t part = (size_t)kMaxParts * nq * p.kp;
   w.part_val = reinterpret_cast<float*>(take(part * 4));
   w.part_idx = reinterpret_cast<int*>(take(part * 4));
   w.pre_val = reinterpret_cast<float*>(take((size_t)nq * p.kp * 4));
@@ -1393,7 +1553,10 @@ void launch_scan(const Plan& p, const ScanArgs& a, int grid_x, hipStream_t st) {
   } else if (p.qb == 32) {
     launch_scan_cfg<T, 16, 1, 1, 4>(a, grid_x, grid_y, st);
   } else if (p.qb == 64) {
-    launch_scan_cfg<T, 16, 2, 1, 4>(a, grid_x, grid_y, st);
+    if (kQ64ThreePerCU)
+      launch_scan_cfg<T, 16, 1, 2, 2>(a, grid_x, grid_y, st);
+    else
+      launch_scan_cfg<T, 16, 2, 1, 4>(a, grid_x, grid_y, st);
   } else {
     launch_scan_cfg<T, 16, 2, 2, 2>(a, grid_x, grid_y, st);
   }
@@ -1654,7 +1817,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m.out_val = out_val;
       m.out_idx = out_idx;
       m.idx_base = idx_base;
-      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
+      launch_merge32(m, st);
       HCIR_LAUNCH_CHECK();
       return HCIR_OK;
     }
@@ -1663,7 +1826,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
     m.kth_val = w.floor_val;
     if (big) m.zero_cnt = w.cand_cnt;  // the big scan's counters and overflow flag start at zero
     if (!prefix_done) {
-      hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m);
+      launch_merge32(m, st);
       HCIR_LAUNCH_CHECK();
     }
     // phase B: rows [prefix, ng) with the prefix k-th score as floor
@@ -1713,12 +1876,13 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       mc.idx_base = idx_base;
       mc.gate = overflow;
       mc.gate_want = 0;
-      hipLaunchKernelGGL(topk_merge32_kernel<kCandLPL>, dim3(merge_grid), dim3(256), 0, st, mc);
+      launch_merge32(mc, st);
       HCIR_LAUNCH_CHECK();
       a.gate = overflow;  // the launches below: fallback only
     }
     const int64_t tiles_b = hcir_cdiv(ng - pp.prefix, p.gm);
-    const int grid_b = scan_grid_x(tiles_b, qblocks);
+    const bool q64g3 = kQ64ThreePerCU && p.kp == 16 && p.qb == 64;
+    const int grid_b = scan_grid_x(tiles_b, qblocks, q64g3 ? kMaxGridQ64 : kMaxGridX);
     launch_scan_dtype(dtype, p, a, grid_b, st);
     HCIR_LAUNCH_CHECK();
     MergeArgs<int> m2{};
@@ -1741,7 +1905,7 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m2.gate = fallback_gate;
       m2.gate_want = 1;
     }
-    hipLaunchKernelGGL(topk_merge32_kernel<kMergeLPL>, dim3(merge_grid), dim3(256), 0, st, m2);
+    launch_merge32(m2, st);
     HCIR_LAUNCH_CHECK();
     return HCIR_OK;
   }

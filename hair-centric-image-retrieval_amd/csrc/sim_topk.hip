@@ -150,6 +150,7 @@ struct ScanArgs {
   int* cand_cnt;      // [nq]
   int* overflow;      // [1]
   int cap;
+  int cand_query_major;  // 1: buffers are [nq][cap] (what the select kernels read, coalesced); 0: [cap][nq]
   int floor_groups;   // floor = min over this many [nq] arrays behind floor_val (group floors of the prefix)
   int floor_inclusive;  // 1: candidates are scores >= floor (the scan covers the rows the floor came from)
 };
@@ -428,8 +429,9 @@ __global__ __launch_bounds__(256, ((KP == 16 && QT == 1 && WQ == 2 && WGG == 2 &
               if ((mask >> i) & 1u) {  // rare behind the floor: one global atomic per candidate
                 const int pos = atomicAdd(a.cand_cnt + myq[qt], 1);
                 if (pos < a.cap) {
-                  a.cand_val[(int64_t)pos * a.nq + myq[qt]] = s;
-                  a.cand_idx[(int64_t)pos * a.nq + myq[qt]] = (int)(rbase + (i & 3) + 8 * (i >> 2));
+                  const int64_t at = a.cand_query_major ? myq[qt] * a.cap + pos : (int64_t)pos * a.nq + myq[qt];
+                  a.cand_val[at] = s;
+                  a.cand_idx[at] = (int)(rbase + (i & 3) + 8 * (i >> 2));
                 } else {
                   *a.overflow = 1;
                 }
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(256) void topk_merge32q_kernel(MergeArgs<int> a) {
 // cap = 64 (LPL - 1).
 // --------------------------------------------------------------------------
 struct SelectArgs {
-  const float* cand_val;
+  const float* cand_val;   // [nq][cap] (query-major: a query's candidates are contiguous)
   const int* cand_idx;
   const int* cand_cnt;
   int cap;
@@ -1222,13 +1224,54 @@ __global__ __launch_bounds__(256) void topk_select_kernel(SelectArgs a) {
   for (int j = 0; j < LPL - 1; ++j) {
     const int e = lane + 64 * j;
     kq[j] = 0ull;
-    if (e < cnt) kq[j] = merge_key(a.cand_val[(int64_t)e * a.nq + qi], a.cand_idx[(int64_t)e * a.nq + qi]);
+    if (e < cnt) kq[j] = merge_key(a.cand_val[qi * a.cap + e], a.cand_idx[qi * a.cap + e]);
   }
   kq[LPL - 1] = 0ull;
   if (a.pre_val && lane < a.kpre) kq[LPL - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
   uint64_t mine;
   int rank;
   const int k = select_keys<LPL>(kq, a.k, lane, compact[wave], mine, rank);
+  if (lane < k) {
+    a.out_val[qi * a.k + rank] = merge_key_val(mine);
+    a.out_idx[qi * a.k + rank] = (int64_t)merge_key_idx(mine) + a.idx_base;
+  } else if (lane < a.k) {   // fewer than k rows in all
+    a.out_val[qi * a.k + lane] = kNegInf;
+    a.out_idx[qi * a.k + lane] = -1;
+  }
+}
+
+// select with FOUR waves per query (big candidate buffers: 16 < k <= 64): wave w selects the k best of candidates
+// w, w + 4, ... (wave 0 also holds the sorted extra list), the four results meet in LDS and wave 0 selects and ranks
+// the k best of those <= 4k keys.  LPLQ = slots per lane of a wave = ceil(cap / 256) + 1.
+template <int LPLQ>
+__global__ __launch_bounds__(256) void topk_select4_kernel(SelectArgs a) {
+  __shared__ uint64_t compact[4][64];
+  __shared__ uint64_t stage[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t qi = blockIdx.x;
+  if (a.gate && ((*a.gate != 0) != (a.gate_want != 0))) return;
+  int cnt = a.cand_cnt[qi];
+  cnt = cnt < a.cap ? cnt : a.cap;
+  uint64_t kq[LPLQ];
+#pragma unroll
+  for (int j = 0; j < LPLQ - 1; ++j) {
+    const int e = 4 * (lane + 64 * j) + wave;
+    kq[j] = 0ull;
+    if (e < cnt) kq[j] = merge_key(a.cand_val[qi * a.cap + e], a.cand_idx[qi * a.cap + e]);
+  }
+  kq[LPLQ - 1] = 0ull;
+  if (wave == 0 && a.pre_val && lane < a.kpre)
+    kq[LPLQ - 1] = merge_key(a.pre_val[qi * a.kpre + lane], a.pre_idx[qi * a.kpre + lane]);
+  uint64_t mine;
+  int rank;
+  select_keys<LPLQ>(kq, a.k, lane, compact[wave], mine, rank);
+  stage[wave][lane] = mine;   // 0 beyond the wave's count
+  __syncthreads();
+  if (wave != 0) return;
+  uint64_t k2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) k2[j] = stage[j][lane];
+  const int k = select_keys<4>(k2, a.k, lane, compact[0], mine, rank);
   if (lane < k) {
     a.out_val[qi * a.k + rank] = merge_key_val(mine);
     a.out_idx[qi * a.k + rank] = (int64_t)merge_key_idx(mine) + a.idx_base;
@@ -1576,7 +1619,7 @@ void launch_cand(int qb, const ScanArgs& a, int grid_x, hipStream_t st) {
   if (qb == 32)
     launch_cand_cfg<T, 1, 1, 4>(a, grid_x, grid_y, st);
   else if (qb == 64)
-    launch_cand_cfg<T, 2, 1, 4>(a, grid_x, grid_y, st);
+    launch_cand_cfg<T, 1, 2, 2>(a, grid_x, grid_y, st);   // 128-row tiles, three workgroups per CU (C5 at 64 queries: 719 -> 706 us)
   else
     launch_cand_cfg<T, 2, 2, 2>(a, grid_x, grid_y, st);
 }
@@ -1710,7 +1753,9 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       c.k = G == 1 ? k : 16;
       c.row_begin = 0;
       c.row_end = S;
-      const int grid_a = scan_grid_x(hcir_cdiv(S, pc.gm), qbl);
+      // (the 16-entry list kernel of 33..64 queries works on 128-row tiles)
+      const int gm_a = (kQ64ThreePerCU && pc.qb == 64) ? 128 : pc.gm;
+      const int grid_a = scan_grid_x(hcir_cdiv(S, gm_a), qbl);
       launch_scan_dtype(dtype, pc, c, grid_a, st);
       HCIR_LAUNCH_CHECK();
       MergeArgs<int> m{};
@@ -1725,7 +1770,10 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       m.kth_val = w.floor_val;
       m.zero_cnt = w.cand_cnt;
       m.ngroups = G;
-      hipLaunchKernelGGL(topk_merge_sel_kernel<kMergeLPL>, dim3(merge_grid, G), dim3(256), 0, st, m);
+      if (G == 1)
+        launch_merge32(m, st);   // four waves per query (the selection merge below: 21.6 us at 32 queries)
+      else
+        hipLaunchKernelGGL(topk_merge_sel_kernel<kMergeLPL>, dim3(merge_grid, G), dim3(256), 0, st, m);
       HCIR_LAUNCH_CHECK();
       int* overflow = w.cand_cnt + nq;
       c.row_begin = G == 1 ? S : 0;
@@ -1738,7 +1786,9 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
       c.cand_cnt = w.cand_cnt;
       c.overflow = overflow;
       c.cap = cap;
-      const int grid_b = scan_grid_x(hcir_cdiv(c.row_end - c.row_begin, pc.gm), qbl);
+      c.cand_query_major = 1;
+      const bool cg3 = pc.qb == 64;   // launch_cand's 64-query geometry: 128-row tiles, up to 768 workgroups
+      const int grid_b = scan_grid_x(hcir_cdiv(c.row_end - c.row_begin, cg3 ? 128 : pc.gm), qbl, cg3 ? 768 : kMaxGridX);
       launch_cand_dtype(dtype, pc.qb, c, grid_b, st);
       HCIR_LAUNCH_CHECK();
       SelectArgs sa{};
@@ -1763,8 +1813,8 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
         hipLaunchKernelGGL(topk_select_kernel<8>, dim3(merge_grid), dim3(256), 0, st, sa);
       else if (k <= 16)
         hipLaunchKernelGGL(topk_select_kernel<kCandLPL>, dim3(merge_grid), dim3(256), 0, st, sa);
-      else
-        hipLaunchKernelGGL(topk_select_kernel<kSelLPLBig>, dim3(merge_grid), dim3(256), 0, st, sa);
+      else   // 3008 candidates: four waves per query, 12 + 1 slots per lane
+        hipLaunchKernelGGL(topk_select4_kernel<(kCandCapBig + 255) / 256 + 1>, dim3((unsigned)nq), dim3(256), 0, st, sa);
       HCIR_LAUNCH_CHECK();
       fallback_gate = overflow;
       prefix_done = G == 1;   // the list flow's phase A is exactly what ran above (same kernel, rows [0, S))

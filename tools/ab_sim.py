@@ -1,6 +1,6 @@
 """A/B of libhcir builds on hcir_sim_topk, interleaved rounds in ONE process (cdna_hip_programming.md §5.4 rule 24).
 usage: python3 tools/ab_sim.py tag=path [tag=path ...]     ('base=' = the in-tree library)
-Cases: 1 M x 768 fp16 (k = 16; 1 / 32 / 64 / 128 queries), 1.25 M x 1024 fp16 top-50 (32 / 64 queries)."""
+Cases: 1 M x 768 fp16 (k = 16; 1 / 32 / 64 / 128 / 880 queries), 1.25 M x 1024 fp16 top-50 (32 / 64 queries)."""
 import ctypes, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hair-centric-image-retrieval_amd"))
@@ -22,7 +22,7 @@ def main():
         tag, _, path = spec.partition("=")
         libs.append((tag, load(path or _lib.LIB_PATH)))
     st = torch.cuda.current_stream().cuda_stream
-    for (ng, d, k, nqs) in ((1_000_000, 768, 16, (1, 32, 64, 128)), (1_250_000, 1024, 50, (32, 64))):
+    for (ng, d, k, nqs) in ((1_000_000, 768, 16, (1, 32, 64, 128, 880)), (1_250_000, 1024, 50, (32, 64))):
         g = torch.empty(ng, d, device="cuda", dtype=torch.float16)
         for s in range(0, ng, 250_000):
             g[s:s + 250_000] = torch.nn.functional.normalize(torch.randn(min(250_000, ng - s), d, device="cuda"), dim=1).half()

@@ -1,0 +1,382 @@
+// jpeg_core.h — the arithmetic of the baseline-JPEG path, shared by the HIP kernels (jpeg.hip) and by the
+// host-compiled emulation that the CPU tests drive (tests/jpeg_emul.cpp: the same functions, a sequential
+// loop in place of the thread grid).  Everything here is plain integer code:
+//   * bit reader over the staged stream (32-bit words in big-endian bit order, stuffing / RSTn removed),
+//   * one Huffman symbol step of the sequential decoder (DC difference, AC run/size, ZRL, EOB) as a pure
+//     function of the decoder state (bit position, block-in-MCU, zigzag index) — which is what makes the
+//     self-synchronising subsequence decode verifiable: two chains are merged iff their states are equal,
+//   * jpeg_idct_islow (CONST_BITS 13, PASS1_BITS 2), libjpeg's post-IDCT range-limit table as arithmetic,
+//   * h2v1 / h2v2 fancy upsampling taps and the YCbCr -> RGB fixed-point tables of libjpeg-turbo.
+// oracle/jpeg.py restates the same pipeline independently (bit-serial Huffman, numpy IDCT) and is pinned to
+// Pillow's libjpeg-turbo 3.1.4; the GPU path is tested against both.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/hcir.h"
+
+#if defined(__HIPCC__)
+#define JHD __host__ __device__ __forceinline__
+#else
+#define JHD inline
+#endif
+
+// zigzag index -> natural (row-major) index; 16 extra entries catch a run that overshoots 63 on a
+// mis-synchronised chain (as jpeg_natural_order does in libjpeg)
+JHD int jpeg_natural(int z) {
+  constexpr uint8_t T[80] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33,
+                             40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36,
+                             29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54,
+                             47, 55, 62, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+  return T[z];
+}
+
+// ---- decoder state ---------------------------------------------------------------------------------------
+struct JState {
+  uint32_t p;        // bit position in the staged stream (always at a symbol boundary, never inside padding)
+  uint32_t c;        // block index inside the MCU
+  uint32_t z;        // zigzag index of the next coefficient (0: the block's DC symbol comes next)
+  uint32_t seg;      // restart segment that contains p (a function of p; kept to avoid searching)
+  uint32_t seg_end;  // first bit behind that segment
+};
+
+// what two chains compare: equal keys => equal futures
+JHD uint64_t jpeg_state_key(const JState& s) { return ((uint64_t)s.p << 16) | (s.c << 8) | s.z; }
+
+struct JStream {
+  const uint32_t* words;      // stream, word i holds bits [32 i, 32 i + 32), first bit in bit 31
+  const uint32_t* seg_start;  // [nseg + 1] start bit of every segment; [nseg] = stream_bits
+  uint32_t nseg, stream_bits, bpm;
+  const hcir_jpeg_hufftab* tabs;  // the header's four tables
+  uint32_t dc_sel, ac_sel;        // 4 bits per block of the MCU: which table (a register, not an indexed array)
+};
+
+JHD void jpeg_stream_tables(const hcir_jpeg_header& h, JStream& J) {
+  J.tabs = h.huff;
+  J.dc_sel = J.ac_sel = 0;
+  for (int i = 0; i < h.blocks_per_mcu && i < 8; ++i) {
+    const int ci = h.blk_comp[i];
+    J.dc_sel |= (uint32_t)h.dc_tab[ci] << (4 * i);
+    J.ac_sel |= (uint32_t)h.ac_tab[ci] << (4 * i);
+  }
+}
+
+JHD uint32_t jpeg_peek32(const uint32_t* w, uint32_t p) {
+  const uint32_t i = p >> 5, s = p & 31;
+  const uint64_t v = ((uint64_t)w[i] << 32) | w[i + 1];
+  return (uint32_t)((v << s) >> 32);
+}
+
+JHD void jpeg_state_at(const JStream& J, uint32_t p, uint32_t c, uint32_t z, JState& s) {
+  s.p = p;
+  s.c = c;
+  s.z = z;
+  uint32_t lo = 0, hi = J.nseg;  // last segment whose start is <= p
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (J.seg_start[mid] <= p) lo = mid; else hi = mid;
+  }
+  s.seg = lo;
+  s.seg_end = J.seg_start[lo + 1];
+  if (p >= J.stream_bits) {
+    s.p = J.stream_bits;
+    s.seg = J.nseg;
+    s.seg_end = J.stream_bits;
+    s.c = s.z = 0;
+  }
+}
+
+// jdhuff.c: 8-bit lookahead, then the maxcode walk for longer codes.  bits32: next 32 stream bits, first in bit 31.
+JHD uint32_t jpeg_huff_symbol(const hcir_jpeg_hufftab* t, uint32_t bits32, uint32_t& nbits) {
+  const uint32_t look = t->look[bits32 >> 24];
+  if (look) {
+    nbits = look >> 8;
+    return look & 0xFF;
+  }
+  uint32_t l = 9;
+  int32_t code = (int32_t)(bits32 >> 23);
+  while (l <= 16 && code > t->maxcode[l]) {
+    code = (code << 1) | (int32_t)((bits32 >> (31 - l)) & 1);
+    ++l;
+  }
+  if (l > 16) {  // no such code: only a chain that is not (yet) synchronised gets here
+    nbits = 16;
+    return 0;
+  }
+  nbits = l;
+  return t->vals[(uint32_t)(code + t->valoff[l]) & 255];
+}
+
+JHD int32_t jpeg_extend(uint32_t v, uint32_t s) {  // HUFF_EXTEND
+  return v < (1u << (s - 1)) ? (int32_t)v - (int32_t)((1u << s) - 1) : (int32_t)v;
+}
+
+struct JNullSink {
+  JHD void dc(int32_t) {}
+  JHD void ac(uint32_t, int32_t) {}
+  JHD void block_done() {}
+  JHD bool finished() const { return false; }
+};
+
+// Decodes every symbol that STARTS before bit `limit`; returns the number of blocks completed.  After each
+// symbol the state is canonicalised: fewer than 8 bits left in the segment and all of them 1 (the encoder's
+// padding — no Huffman code is all ones, ITU T.81 Annex C) or the segment exhausted => continue at the next
+// segment's first bit with (c, z) = (0, 0).
+template <class Sink>
+JHD uint32_t jpeg_decode_span(const JStream& J, JState& s, uint32_t limit, Sink& sink) {
+  uint32_t nblk = 0;
+  while (s.p < limit && !sink.finished()) {
+    const uint32_t bits = jpeg_peek32(J.words, s.p);
+    uint32_t nb;
+    if (s.z == 0) {
+      const uint32_t ssss = jpeg_huff_symbol(J.tabs + ((J.dc_sel >> (4 * s.c)) & 15), bits, nb) & 15;
+      int32_t diff = 0;
+      if (ssss) diff = jpeg_extend((bits << nb) >> (32 - ssss), ssss);
+      s.p += nb + ssss;
+      sink.dc(diff);
+      s.z = 1;
+    } else {
+      const uint32_t rs = jpeg_huff_symbol(J.tabs + ((J.ac_sel >> (4 * s.c)) & 15), bits, nb);
+      const uint32_t r = rs >> 4, ssss = rs & 15;
+      if (ssss) {
+        s.z += r;
+        sink.ac(s.z, jpeg_extend((bits << nb) >> (32 - ssss), ssss));
+        s.z += 1;
+        s.p += nb + ssss;
+      } else {
+        s.z = (r == 15) ? s.z + 16 : 64;
+        s.p += nb;
+      }
+    }
+    if (s.z >= 64) {
+      s.z = 0;
+      s.c = (s.c + 1 == J.bpm) ? 0 : s.c + 1;
+      ++nblk;
+      sink.block_done();
+    }
+    if (s.p + 8 > s.seg_end) {
+      bool jump = s.p >= s.seg_end;
+      if (!jump) {
+        const uint32_t rem = s.seg_end - s.p;
+        jump = (jpeg_peek32(J.words, s.p) >> (32 - rem)) == ((1u << rem) - 1);
+      }
+      if (jump) {
+        s.seg += 1;
+        s.c = s.z = 0;
+        if (s.seg >= J.nseg) {
+          s.seg = J.nseg;
+          s.p = s.seg_end = J.stream_bits;
+        } else {
+          s.p = J.seg_start[s.seg];
+          s.seg_end = J.seg_start[s.seg + 1];
+        }
+      }
+    }
+  }
+  return nblk;
+}
+
+// ---- window geometry ------------------------------------------------------------------------------------
+struct JWin {
+  int32_t x0, y0;              // image coordinates of output pixel (0, 0); negative when the image is padded
+  int32_t mx0, my0, nmx, nmy;  // MCU rectangle that is reconstructed (empty: nmx == 0)
+  int32_t last_mcu;            // scan-order index of the last MCU needed, -1 if none
+  int32_t wblocks;             // blocks in the rectangle = nmx * nmy * blocks_per_mcu
+};
+
+JHD int32_t jpeg_pyround_half(int32_t num) {  // Python round(num / 2.0): ties to even
+  if ((num & 1) == 0) return num / 2;
+  const int32_t lo = (num - 1) / 2;
+  return (lo & 1) ? lo + 1 : lo;
+}
+
+// torchvision center_crop((win_h, win_w)): pad to the window, crop at round((dim' - win) / 2)
+JHD void jpeg_window(const hcir_jpeg_header& h, int32_t win_h, int32_t win_w, JWin& w) {
+  const int32_t ph = h.height < win_h ? win_h - h.height : 0, pw = h.width < win_w ? win_w - h.width : 0;
+  w.y0 = jpeg_pyround_half(h.height + ph - win_h) - ph / 2;
+  w.x0 = jpeg_pyround_half(h.width + pw - win_w) - pw / 2;
+  // pixels of the image the window shows, widened by one chroma sample for the triangle filter
+  int32_t xa = w.x0 - (h.hmax > 1 ? h.hmax : 0), xb = w.x0 + win_w - 1 + (h.hmax > 1 ? h.hmax : 0);
+  int32_t ya = w.y0 - (h.vmax > 1 ? h.vmax : 0), yb = w.y0 + win_h - 1 + (h.vmax > 1 ? h.vmax : 0);
+  xa = xa < 0 ? 0 : xa;
+  ya = ya < 0 ? 0 : ya;
+  xb = xb > h.width - 1 ? h.width - 1 : xb;
+  yb = yb > h.height - 1 ? h.height - 1 : yb;
+  if (xb < xa || yb < ya) {
+    w.mx0 = w.my0 = w.nmx = w.nmy = 0;
+    w.last_mcu = -1;
+    w.wblocks = 0;
+    return;
+  }
+  const int32_t mw = 8 * h.hmax, mh = 8 * h.vmax;
+  w.mx0 = xa / mw;
+  w.my0 = ya / mh;
+  w.nmx = xb / mw - w.mx0 + 1;
+  w.nmy = yb / mh - w.my0 + 1;
+  w.last_mcu = (w.my0 + w.nmy - 1) * h.mcus_x + w.mx0 + w.nmx - 1;
+  w.wblocks = w.nmx * w.nmy * h.blocks_per_mcu;
+}
+
+// slot of scan-order block b inside the window's coefficient buffer, -1 when its MCU lies outside
+JHD int32_t jpeg_window_slot(const hcir_jpeg_header& h, const JWin& w, uint32_t b) {
+  const uint32_t mcu = b / (uint32_t)h.blocks_per_mcu, blk = b - mcu * (uint32_t)h.blocks_per_mcu;
+  const int32_t my = (int32_t)(mcu / (uint32_t)h.mcus_x), mx = (int32_t)(mcu - (uint32_t)my * (uint32_t)h.mcus_x);
+  const int32_t ry = my - w.my0, rx = mx - w.mx0;
+  if (ry < 0 || ry >= w.nmy || rx < 0 || rx >= w.nmx) return -1;
+  return (ry * w.nmx + rx) * h.blocks_per_mcu + (int32_t)blk;
+}
+
+// ---- jidctint.c: jpeg_idct_islow ------------------------------------------------------------------------
+JHD int32_t jpeg_descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// one 8-point pass; in/out strides let the same code run down columns (pass 1) and along rows (pass 2)
+JHD void jpeg_idct8(const int32_t* in, int istride, int32_t* out, int ostride, int shift) {
+  constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
+                    F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+  int32_t z2 = in[2 * istride], z3 = in[6 * istride];
+  int32_t z1 = (z2 + z3) * F0_541;
+  const int32_t tmp2 = z1 + z3 * (-F1_847);
+  const int32_t tmp3 = z1 + z2 * F0_765;
+  z2 = in[0];
+  z3 = in[4 * istride];
+  const int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << 13);
+  const int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << 13);
+  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  int32_t t0 = in[7 * istride], t1 = in[5 * istride], t2 = in[3 * istride], t3 = in[1 * istride];
+  z1 = t0 + t3;
+  z2 = t1 + t2;
+  z3 = t0 + t2;
+  int32_t z4 = t1 + t3;
+  const int32_t z5 = (z3 + z4) * F1_175;
+  t0 *= F0_298;
+  t1 *= F2_053;
+  t2 *= F3_072;
+  t3 *= F1_501;
+  z1 *= -F0_899;
+  z2 *= -F2_562;
+  z3 = z3 * (-F1_961) + z5;
+  z4 = z4 * (-F0_390) + z5;
+  t0 += z1 + z3;
+  t1 += z2 + z4;
+  t2 += z2 + z3;
+  t3 += z1 + z4;
+  out[0 * ostride] = jpeg_descale(tmp10 + t3, shift);
+  out[7 * ostride] = jpeg_descale(tmp10 - t3, shift);
+  out[1 * ostride] = jpeg_descale(tmp11 + t2, shift);
+  out[6 * ostride] = jpeg_descale(tmp11 - t2, shift);
+  out[2 * ostride] = jpeg_descale(tmp12 + t1, shift);
+  out[5 * ostride] = jpeg_descale(tmp12 - t1, shift);
+  out[3 * ostride] = jpeg_descale(tmp13 + t0, shift);
+  out[4 * ostride] = jpeg_descale(tmp13 - t0, shift);
+}
+
+// range_limit[x & RANGE_MASK] with the post-IDCT table of jdmaster.c prepare_range_limit_table
+JHD uint8_t jpeg_range_limit(int32_t v) {
+  const uint32_t i = (uint32_t)v & 1023u;
+  return (uint8_t)(i < 128 ? i + 128 : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+}
+
+// ---- jdcolor.c: ycc_rgb_convert ---------------------------------------------------------------------------
+JHD uint8_t jpeg_clamp8(int32_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+JHD void jpeg_ycc_rgb(int32_t y, int32_t cb, int32_t cr, uint8_t* rgb) {
+  constexpr int32_t FIX_1_40200 = 91881, FIX_1_77200 = 116130, FIX_0_71414 = 46802, FIX_0_34414 = 22554;
+  const int32_t xb = cb - 128, xr = cr - 128;
+  rgb[0] = jpeg_clamp8(y + ((FIX_1_40200 * xr + 32768) >> 16));
+  rgb[1] = jpeg_clamp8(y + ((-FIX_0_34414 * xb + 32768 - FIX_0_71414 * xr) >> 16));
+  rgb[2] = jpeg_clamp8(y + ((FIX_1_77200 * xb + 32768) >> 16));
+}
+
+// ---- jdsample.c: one output sample of a chroma plane at full-resolution pixel (x, y) -------------------------
+// plane: window plane of the component (pitch `pitch`, origin (px0, py0) in the component's own grid);
+// dw x dh: the component's REAL size (ceil(width * h / hmax)): neighbours clamp to it, which is what libjpeg's
+// edge handling (first / last column special cases, replicated context rows) amounts to.
+JHD int32_t jpeg_upsampled(const uint8_t* plane, int32_t pitch, int32_t px0, int32_t py0, int32_t dw, int32_t dh,
+                           int32_t fx, int32_t fy, int32_t x, int32_t y) {
+  if (fx == 1 && fy == 1) return plane[(y - py0) * pitch + (x - px0)];
+  const int32_t cx = x >> 1, cy = fy == 2 ? y >> 1 : y;
+  if (dw <= 2) return plane[(cy - py0) * pitch + (cx - px0)];  // jinit_upsampler: no fancy path, box replication
+  int32_t cxn = (x & 1) ? cx + 1 : cx - 1;
+  cxn = cxn < 0 ? 0 : (cxn > dw - 1 ? dw - 1 : cxn);
+  const uint8_t* r0 = plane + (cy - py0) * pitch - px0;
+  if (fy == 1) {
+    const int32_t cur = r0[cx], oth = r0[cxn];
+    return (x & 1) ? (3 * cur + oth + 2) >> 2 : (3 * cur + oth + 1) >> 2;
+  }
+  int32_t cyn = (y & 1) ? cy + 1 : cy - 1;
+  cyn = cyn < 0 ? 0 : (cyn > dh - 1 ? dh - 1 : cyn);
+  const uint8_t* r1 = plane + (cyn - py0) * pitch - px0;
+  const int32_t thiscol = 3 * r0[cx] + r1[cx], othcol = 3 * r0[cxn] + r1[cxn];
+  return (x & 1) ? (3 * thiscol + othcol + 7) >> 4 : (3 * thiscol + othcol + 8) >> 4;
+}
+
+// ---- the write pass's sink: DC differences of every block up to the last one needed, AC coefficients of the
+// blocks whose MCU lies in the window rectangle -------------------------------------------------------------------
+struct JWriteSink {
+  const hcir_jpeg_header* h;
+  const JWin* w;
+  int16_t* dcdiff;  // [last_block + 1] in scan order
+  int16_t* coef;    // [wblocks][64] natural order, zero-filled by the caller
+  uint32_t b;       // scan-order index of the block being decoded
+  uint32_t last_block;
+  int32_t slot;
+  JHD void begin(uint32_t b0) {
+    b = b0;
+    slot = b <= last_block ? jpeg_window_slot(*h, *w, b) : -1;
+  }
+  JHD void dc(int32_t d) {
+    if (b <= last_block) dcdiff[b] = (int16_t)d;
+  }
+  JHD void ac(uint32_t z, int32_t v) {
+    if (slot >= 0) coef[slot * 64 + jpeg_natural((int)z)] = (int16_t)v;
+  }
+  JHD void block_done() {
+    ++b;
+    slot = b <= last_block ? jpeg_window_slot(*h, *w, b) : -1;
+  }
+  JHD bool finished() const { return b > last_block; }
+};
+
+// one block: dequantise, two islow passes, range limit; out = 8 rows of 8 samples at `pitch`
+JHD void jpeg_idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int32_t pitch) {
+  int32_t ws[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) ws[i] = (int32_t)coef[i] * (int32_t)q[i];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) jpeg_idct8(ws + c, 8, ws + c, 8, 13 - 2);       // columns, keep PASS1_BITS
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    int32_t px[8];
+    jpeg_idct8(ws + 8 * r, 1, px, 1, 13 + 2 + 3);                              // rows, /8 and drop PASS1_BITS
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[r * pitch + c] = jpeg_range_limit(px[c]);
+  }
+}
+
+// geometry of component ci's window plane
+struct JPlane {
+  int32_t pitch, rows;  // samples
+  int32_t px0, py0;     // origin in the component's own sample grid
+  int32_t dw, dh;       // real size of the component (neighbour clamp)
+  int32_t fx, fy;       // upsampling factors to full resolution
+};
+JHD void jpeg_plane(const hcir_jpeg_header& h, const JWin& w, int ci, JPlane& p) {
+  p.pitch = w.nmx * h.hs[ci] * 8;
+  p.rows = w.nmy * h.vs[ci] * 8;
+  p.px0 = w.mx0 * h.hs[ci] * 8;
+  p.py0 = w.my0 * h.vs[ci] * 8;
+  p.dw = (h.width * h.hs[ci] + h.hmax - 1) / h.hmax;
+  p.dh = (h.height * h.vs[ci] + h.vmax - 1) / h.vmax;
+  p.fx = h.hmax / h.hs[ci];
+  p.fy = h.vmax / h.vs[ci];
+}
+// where block `slot` of the coefficient buffer lands: component and top-left sample inside that component's plane
+JHD void jpeg_block_place(const hcir_jpeg_header& h, const JWin& w, int32_t slot, int& ci, int32_t& sx, int32_t& sy) {
+  const int32_t wm = slot / h.blocks_per_mcu, blk = slot - wm * h.blocks_per_mcu;
+  const int32_t ry = wm / w.nmx, rx = wm - ry * w.nmx;
+  ci = h.blk_comp[blk];
+  int32_t first = 0;  // index of the component's first block inside the MCU
+  for (int c = 0; c < ci; ++c) first += h.hs[c] * h.vs[c];
+  const int32_t k = blk - first, by = k / h.hs[ci], bx = k - by * h.hs[ci];
+  sx = (rx * h.hs[ci] + bx) * 8;
+  sy = (ry * h.vs[ci] + by) * 8;
+}

@@ -1,0 +1,264 @@
+// jpeg_stage.h — HOST side of the JPEG path: marker walk + staging copy (hcir_jpeg_stage).  Plain C++ (no HIP),
+// so that the CPU tests compile the very same parser (tests/jpeg_emul.cpp).
+//
+// What the reference's decoders do here is libjpeg's jdmarker.c (read_markers, get_sof, get_dht, get_dqt,
+// get_dri, get_sos) and jdhuff.c's jpeg_make_d_derived_tbl; behind HP/utils/dataloader.py:28-31
+// (torchvision.io.decode_image) and src/models/hair_encoder.py:108 (PIL).  The staging copy replaces the
+// byte-at-a-time unstuffing of jdhuff.c's fill_bit_buffer: one pass that drops the zero after every FF and the
+// RSTn markers, records where every restart segment starts, and packs the bytes into 32-bit words whose bit 31
+// is the first stream bit (the device reads two words and shifts).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/hcir.h"
+
+namespace jpeg_host {
+
+inline uint32_t be16(const uint8_t* p) { return ((uint32_t)p[0] << 8) | p[1]; }
+
+static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// jpeg_make_d_derived_tbl: canonical codes from BITS / HUFFVAL; 8-bit lookahead table
+inline int derive_table(const uint8_t bits[16], const uint8_t* vals, int nvals, hcir_jpeg_hufftab* t) {
+  memset(t, 0, sizeof(*t));
+  uint8_t size[257];
+  uint32_t code_of[257];
+  int p = 0;
+  for (int l = 1; l <= 16; ++l)
+    for (int i = 0; i < bits[l - 1]; ++i) {
+      if (p >= 256) return HCIR_ERR_INVALID;
+      size[p++] = (uint8_t)l;
+    }
+  if (p != nvals) return HCIR_ERR_INVALID;
+  uint32_t code = 0;
+  int si = p ? size[0] : 0, k = 0;
+  while (k < p) {
+    while (k < p && size[k] == si) code_of[k++] = code++;
+    if (code > (1u << si)) return HCIR_ERR_INVALID;  // more codes of this length than fit
+    code <<= 1;
+    ++si;
+  }
+  k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    if (bits[l - 1]) {
+      t->valoff[l] = k - (int32_t)code_of[k];
+      k += bits[l - 1];
+      t->maxcode[l] = (int32_t)code_of[k - 1];
+    } else {
+      t->maxcode[l] = -1;
+    }
+  }
+  t->maxcode[17] = 0xFFFFF;
+  t->maxcode[0] = -1;
+  k = 0;
+  for (int l = 1; l <= 8; ++l)
+    for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+      const uint32_t first = code_of[k] << (8 - l);
+      for (uint32_t j = 0; j < (1u << (8 - l)); ++j) t->look[first + j] = (uint16_t)((l << 8) | vals[k]);
+    }
+  memcpy(t->vals, vals, (size_t)nvals);
+  return HCIR_OK;
+}
+
+struct Scan {
+  const uint8_t* data;  // first entropy-coded byte
+  size_t nbytes;        // up to (excluding) the first marker that is neither RSTn nor a stuffed FF
+};
+
+// Marker walk.  Fills everything of *h except the stream fields; *scan = the entropy-coded bytes.
+inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
+  if (!f || n < 4 || f[0] != 0xFF || f[1] != 0xD8) return HCIR_ERR_INVALID;
+  memset(h, 0, sizeof(*h));
+  uint16_t qt[4][64];
+  bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false}, have_sof = false;
+  int comp_id[3] = {0, 0, 0}, comp_tq[3] = {0, 0, 0};
+  size_t i = 2;
+  for (;;) {
+    if (i + 4 > n || f[i] != 0xFF) return HCIR_ERR_INVALID;
+    while (i + 1 < n && f[i + 1] == 0xFF) ++i;  // fill bytes
+    if (i + 4 > n) return HCIR_ERR_INVALID;
+    const uint8_t m = f[i + 1];
+    i += 2;
+    if (m == 0xD9 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) return HCIR_ERR_INVALID;  // EOI / RST / TEM before SOS
+    const size_t len = be16(f + i);
+    if (len < 2 || i + len > n) return HCIR_ERR_INVALID;
+    const uint8_t* s = f + i + 2;
+    const size_t sl = len - 2;
+    if (m == 0xDB) {
+      size_t j = 0;
+      while (j < sl) {
+        const int pq = s[j] >> 4, tq = s[j] & 15;
+        if (tq > 3 || pq > 1) return HCIR_ERR_INVALID;
+        if (j + 1 + (pq ? 128 : 64) > sl) return HCIR_ERR_INVALID;
+        for (int k = 0; k < 64; ++k)
+          qt[tq][kZigzag[k]] = pq ? (uint16_t)be16(s + j + 1 + 2 * k) : s[j + 1 + k];
+        have_qt[tq] = true;
+        j += 1 + (pq ? 128 : 64);
+      }
+    } else if (m == 0xC4) {
+      size_t j = 0;
+      while (j < sl) {
+        if (j + 17 > sl) return HCIR_ERR_INVALID;
+        const int tc = s[j] >> 4, th = s[j] & 15;
+        int cnt = 0;
+        for (int k = 0; k < 16; ++k) cnt += s[j + 1 + k];
+        if (tc > 1 || cnt > 256 || j + 17 + cnt > sl) return HCIR_ERR_INVALID;
+        if (th > 1) return HCIR_ERR_UNSUPPORTED;  // baseline allows table ids 0 and 1
+        const int rc = derive_table(s + j + 1, s + j + 17, cnt, &h->huff[tc * 2 + th]);
+        if (rc != HCIR_OK) return rc;
+        have_ht[tc * 2 + th] = true;
+        j += 17 + cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (sl < 6 || have_sof) return HCIR_ERR_INVALID;
+      if (s[0] != 8) return HCIR_ERR_UNSUPPORTED;
+      h->height = (int32_t)be16(s + 1);
+      h->width = (int32_t)be16(s + 3);
+      h->ncomp = s[5];
+      if (h->height == 0 || h->width == 0) return HCIR_ERR_UNSUPPORTED;  // DNL-defined height
+      if (h->ncomp != 1 && h->ncomp != 3) return HCIR_ERR_UNSUPPORTED;
+      if (sl < (size_t)(6 + 3 * h->ncomp)) return HCIR_ERR_INVALID;
+      for (int c = 0; c < h->ncomp; ++c) {
+        comp_id[c] = s[6 + 3 * c];
+        h->hs[c] = s[7 + 3 * c] >> 4;
+        h->vs[c] = s[7 + 3 * c] & 15;
+        comp_tq[c] = s[8 + 3 * c];
+        if (comp_tq[c] > 3) return HCIR_ERR_INVALID;
+      }
+      have_sof = true;
+    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return HCIR_ERR_UNSUPPORTED;  // progressive, lossless, arithmetic, hierarchical
+    } else if (m == 0xCC) {
+      return HCIR_ERR_UNSUPPORTED;  // DAC: arithmetic conditioning
+    } else if (m == 0xDD) {
+      if (sl < 2) return HCIR_ERR_INVALID;
+      h->restart_interval = (int32_t)be16(s);
+    } else if (m == 0xDA) {
+      if (!have_sof || sl < 1) return HCIR_ERR_INVALID;
+      const int ns = s[0];
+      if (ns != h->ncomp) return HCIR_ERR_UNSUPPORTED;  // non-interleaved / multi-scan
+      if (sl < (size_t)(1 + 2 * ns + 3)) return HCIR_ERR_INVALID;
+      for (int k = 0; k < ns; ++k) {
+        if (s[1 + 2 * k] != comp_id[k]) return HCIR_ERR_UNSUPPORTED;  // components out of frame order
+        const int td = s[2 + 2 * k] >> 4, ta = s[2 + 2 * k] & 15;
+        if (td > 1 || ta > 1) return HCIR_ERR_UNSUPPORTED;
+        if (!have_ht[td] || !have_ht[2 + ta]) return HCIR_ERR_INVALID;
+        h->dc_tab[k] = (uint8_t)td;
+        h->ac_tab[k] = (uint8_t)(2 + ta);
+      }
+      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return HCIR_ERR_UNSUPPORTED;
+      i += len;
+      break;
+    }
+    i += len;
+  }
+  // frame geometry
+  if (h->ncomp == 1) {
+    h->hs[0] = h->vs[0] = 1;  // a one-component scan is not interleaved: its MCU is one block (T.81 A.2.2)
+  } else {
+    const bool ok = h->hs[1] == 1 && h->vs[1] == 1 && h->hs[2] == 1 && h->vs[2] == 1 &&
+                    ((h->hs[0] == 1 && h->vs[0] == 1) || (h->hs[0] == 2 && h->vs[0] == 1) ||
+                     (h->hs[0] == 2 && h->vs[0] == 2));
+    if (!ok) return HCIR_ERR_UNSUPPORTED;
+  }
+  h->hmax = h->hs[0];
+  h->vmax = h->vs[0];
+  h->mcus_x = (h->width + 8 * h->hmax - 1) / (8 * h->hmax);
+  h->mcus_y = (h->height + 8 * h->vmax - 1) / (8 * h->vmax);
+  int nb = 0;
+  for (int c = 0; c < h->ncomp; ++c) {
+    if (!have_qt[comp_tq[c]]) return HCIR_ERR_INVALID;
+    memcpy(h->quant[c], qt[comp_tq[c]], sizeof(qt[0]));
+    for (int k = 0; k < h->hs[c] * h->vs[c]; ++k) h->blk_comp[nb++] = (uint8_t)c;
+  }
+  h->blocks_per_mcu = nb;
+  const int64_t mcus = (int64_t)h->mcus_x * h->mcus_y;
+  if (mcus * nb >= (int64_t(1) << 31)) return HCIR_ERR_UNSUPPORTED;
+  h->nsegments = h->restart_interval > 0 ? (int32_t)((mcus + h->restart_interval - 1) / h->restart_interval) : 1;
+  // entropy-coded segment: ends at the first FF that is followed by neither 00, RSTn nor another FF
+  scan->data = f + i;
+  size_t e = i;
+  while (e < n) {
+    const uint8_t* q = (const uint8_t*)memchr(f + e, 0xFF, n - e);
+    if (!q) {
+      e = n;
+      break;
+    }
+    e = (size_t)(q - f);
+    if (e + 1 >= n) break;
+    const uint8_t nb2 = f[e + 1];
+    if (nb2 == 0x00 || (nb2 >= 0xD0 && nb2 <= 0xD7)) e += 2;
+    else if (nb2 == 0xFF) e += 1;
+    else break;
+  }
+  scan->nbytes = e - i;
+  return HCIR_OK;
+}
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// upper bound of the staged size: every scan byte kept, + 2 pad words, + the segment table
+inline size_t stage_bound(const hcir_jpeg_header& h, const Scan& s) {
+  return align16(((s.nbytes + 3) / 4 + 2) * 4) + align16(((size_t)h.nsegments + 1) * 4);
+}
+
+// The staging copy.  dst must hold stage_bound() bytes.  Returns HCIR_OK and fills stream_bits / stream_words.
+inline int stage(hcir_jpeg_header* h, const Scan& s, uint8_t* dst, size_t* used) {
+  const size_t words_cap = (s.nbytes + 3) / 4 + 2;
+  (void)words_cap;
+  uint32_t* w = reinterpret_cast<uint32_t*>(dst);
+  std::vector<uint32_t> seg;
+  seg.reserve((size_t)h->nsegments + 1);
+  const uint8_t* p = s.data;
+  const uint8_t* end = s.data + s.nbytes;
+  size_t nout = 0;  // bytes emitted
+  uint32_t acc = 0;
+  seg.push_back(0);
+  auto emit = [&](const uint8_t* q, size_t cnt) {
+    for (size_t k = 0; k < cnt; ++k) {
+      acc = (acc << 8) | q[k];
+      if ((++nout & 3) == 0) w[nout / 4 - 1] = acc;
+    }
+  };
+  while (p < end) {
+    const uint8_t* q = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
+    if (!q) {
+      emit(p, (size_t)(end - p));
+      break;
+    }
+    emit(p, (size_t)(q - p));
+    if (q + 1 >= end) break;  // a lone FF at the very end belongs to the next marker
+    const uint8_t nb = q[1];
+    if (nb == 0x00) {
+      const uint8_t ff = 0xFF;
+      emit(&ff, 1);
+      p = q + 2;
+    } else if (nb >= 0xD0 && nb <= 0xD7) {
+      if ((int64_t)seg.size() >= h->nsegments) return HCIR_ERR_INVALID;  // more RSTn than the frame has intervals
+      seg.push_back((uint32_t)(nout * 8));
+      p = q + 2;
+    } else {
+      p = q + 1;  // fill byte in front of a marker
+    }
+  }
+  if (nout * 8 >= (uint64_t(1) << 31)) return HCIR_ERR_UNSUPPORTED;
+  h->stream_bits = (uint32_t)(nout * 8);
+  // a stream with fewer RSTn than intervals (truncated file): the missing segments are empty
+  while ((int64_t)seg.size() <= h->nsegments) seg.push_back(h->stream_bits);
+  // pad with 1-bits: the last partial word plus two whole words (the reader looks 64 bits ahead)
+  const uint8_t ff = 0xFF;
+  while (nout & 3) emit(&ff, 1);
+  for (int k = 0; k < 8; ++k) emit(&ff, 1);
+  h->stream_words = (uint32_t)(nout / 4);
+  // segment table right behind the words (16-byte aligned): the device finds it from stream_words
+  memcpy(dst + align16(nout), seg.data(), seg.size() * 4);
+  *used = align16(nout) + align16(seg.size() * 4);
+  return HCIR_OK;
+}
+
+}  // namespace jpeg_host

@@ -402,6 +402,78 @@ int hcir_mse_bwd(const float* x, const float* y, int64_t n, const float* grad_ou
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * Baseline-JPEG decode on the device.  Replaces
+ *   read_file + torchvision.io.decode_image(img_bytes, mode=RGB)      HP/utils/dataloader.py:28-31
+ *   PIL.Image.open(path).convert('RGB')                               src/models/hair_encoder.py:108,169
+ * in front of knn_transform's CenterCrop (HP/utils/transform.py:11): only the window is reconstructed.
+ * Output bytes equal libjpeg-turbo's default decompressor (islow IDCT, fancy upsampling, its YCbCr
+ * tables) — what both reference decoders link.
+ *
+ * Scope: baseline / extended sequential Huffman, 8-bit, one interleaved scan, grey or YCbCr with luma
+ * sampling 1x1 (4:4:4), 2x1 (4:2:2) or 2x2 (4:2:0) and 1x1 chroma, with or without restart intervals.
+ * Everything else (progressive, arithmetic, 12-bit, CMYK, 4:4:0, 4:1:1, multi-scan) is
+ * HCIR_ERR_UNSUPPORTED from hcir_jpeg_stage and the loader keeps its host decoder for that file.
+ *
+ * Two steps.  (1) HOST: hcir_jpeg_stage parses the markers of one file into a header (frame geometry,
+ * quantisation tables in natural order, derived Huffman tables) and copies the entropy-coded bytes into the
+ * caller's (pinned) staging blob with byte stuffing (FF 00) and RSTn markers removed: the copy a loader
+ * makes into pinned memory anyway.  The blob for a batch is
+ *     [ hcir_jpeg_header x b ][ image 0: stream words | segment table ][ image 1 ... ]
+ * with header.stage_offset = byte offset of the image's stream inside the blob.  (2) DEVICE: after ONE
+ * H2D copy of the blob, hcir_jpeg_decode_window_u8 runs, per image, a workgroup that Huffman-decodes the
+ * stream with one thread per fixed-size subsequence (speculative decode, then the self-synchronisation
+ * hand-over of Weissenberger & Schmidt until every subsequence's start state is verified against its
+ * predecessor's chain), prefix-sums the DC differences, and two small kernels for IDCT and
+ * upsampling + colour conversion of the MCUs the window touches.
+ * ------------------------------------------------------------------ */
+typedef struct hcir_jpeg_hufftab {
+  uint16_t look[256];  /* (code length << 8) | symbol for codes of <= 8 bits, else 0 */
+  int32_t maxcode[18]; /* largest code of length l, -1 if none; [17] = sentinel        */
+  int32_t valoff[17];  /* symbol index = code + valoff[l]                              */
+  uint8_t vals[256];
+} hcir_jpeg_hufftab;
+
+typedef struct hcir_jpeg_header {
+  int32_t width, height, ncomp;
+  int32_t hmax, vmax;
+  int32_t hs[3], vs[3];         /* sampling factors as decoded (a grey image is 1x1)   */
+  int32_t mcus_x, mcus_y, blocks_per_mcu;
+  int32_t restart_interval;     /* MCUs per restart segment, 0 = none                   */
+  int32_t nsegments;            /* entropy-coded segments (restart intervals), >= 1     */
+  uint32_t stream_bits;         /* bits of the staged stream (segments concatenated)    */
+  uint32_t stream_words;        /* 32-bit words staged, incl. 2 words of 1-bit padding  */
+  uint64_t stage_offset;        /* byte offset of the stream inside the staging blob    */
+  uint8_t blk_comp[12];         /* component of block i of an MCU                       */
+  uint8_t dc_tab[4], ac_tab[4]; /* per component: index into huff[] (DC 0-1, AC 2-3)    */
+  uint16_t quant[3][64];        /* per component, natural (row-major) order             */
+  hcir_jpeg_hufftab huff[4];
+} hcir_jpeg_header;
+
+/* HOST.  Bytes of staging blob needed for this file's stream + segment table (0 if not a JPEG). */
+size_t hcir_jpeg_stage_bytes(const uint8_t* file, size_t nbytes);
+/* HOST.  Parse `file`, fill *hdr, write the unstuffed stream (big-endian 32-bit words) and the segment
+ * table (uint32 start bit of each segment, nsegments + 1 entries) at blob + blob_offset (multiple of 16);
+ * *used = bytes written (multiple of 16).  HCIR_ERR_UNSUPPORTED / HCIR_ERR_INVALID (corrupt) /
+ * HCIR_ERR_WORKSPACE (cap too small). */
+int hcir_jpeg_stage(const uint8_t* file, size_t nbytes, hcir_jpeg_header* hdr, uint8_t* blob,
+                    size_t blob_offset, size_t blob_cap, size_t* used);
+/* HOST.  The same for b files into one blob (headers at blob[0 .. b * sizeof(hcir_jpeg_header)), streams behind),
+ * `nthreads` worker threads.  status[i] = per-file result; a rejected file gets a zeroed header (width 0), which
+ * hcir_jpeg_decode_window_u8 skips (its window stays zero; the loader decodes that file on the host).
+ * blob == NULL: only *blob_used (bytes to allocate) and status[] are produced. */
+int hcir_jpeg_stage_batch(const uint8_t* const* files, const size_t* nbytes, int64_t b, uint8_t* blob,
+                          size_t blob_cap, size_t* blob_used, int32_t* status, int32_t nthreads);
+/* HOST.  Workspace bytes for a batch (per-image strides are the maxima over the batch). */
+size_t hcir_jpeg_workspace_bytes(const hcir_jpeg_header* hdrs_host, int64_t b, int32_t win_h, int32_t win_w);
+/* blob_dev: DEVICE copy of the staging blob (headers first); hdrs_host: the same headers on the host (grid
+ * sizing only).  out [b][win_h][win_w][3] uint8 = the CenterCrop((win_h, win_w)) window of every decoded
+ * image, zero where the window leaves the image (torchvision pads before cropping).  status_dev [b]
+ * int32 (may be NULL): 0, or a negative hcir_status when a stream did not decode to the frame's block count. */
+int hcir_jpeg_decode_window_u8(const void* blob_dev, const hcir_jpeg_header* hdrs_host, int64_t b, int32_t win_h,
+                               int32_t win_w, uint8_t* out, int32_t* status_dev, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,15 @@
 
 namespace {
 
-constexpr int kHuffThreads = 1024;
+// what the IDCT / colour kernels need of an image, computed once by its Huffman workgroup
+struct JGeom {
+  JWin w;
+  JPlane pl[3];
+  int32_t plane_off[3];  // byte offset of each component's plane inside the image's plane buffer
+  int32_t ncomp, width, height;
+  int32_t rounds;        // hand-over rounds its synchronisation took (diagnostic)
+  uint32_t stamp[6];     // -DHCIR_JPEG_STAMPS: s_memrealtime (100 MHz) at the phase boundaries of the Huffman kernel
+};
 
 struct JpegBatch {
   const uint8_t* blob;  // device: headers, then streams
@@ -47,16 +55,20 @@ struct JpegBatch {
   int16_t* coef;    // [b][coef_stride]
   int16_t* dcdiff;  // [b][dc_stride]
   uint8_t* planes;  // [b][plane_stride]
-  int64_t coef_stride, dc_stride, plane_stride;  // elements
+  JGeom* geom;      // [b]
+  uint32_t* ilv;    // [b][ilv_stride] streams re-laid interleaved by subsequence
+  int64_t coef_stride, dc_stride, plane_stride, ilv_stride;  // elements
+  int32_t huff_threads;
 };
 
 __device__ __forceinline__ const hcir_jpeg_header* hdr_of(const JpegBatch& a, int64_t img) {
   return reinterpret_cast<const hcir_jpeg_header*>(a.blob) + img;
 }
 
-// inclusive scan of one uint32 per thread over the workgroup (blockDim.x a multiple of 64, <= 1024)
-__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wave_tot /* LDS [16] */) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// inclusive scan of one uint32 per thread over the workgroup (blockDim.x a multiple of 64, <= 1024); the
+// workgroup's total is left in wave_tot[16].  Two barriers.
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* wave_tot /* LDS [17] */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t u = __shfl_up(v, o);
@@ -66,47 +78,124 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* w
   __syncthreads();
   uint32_t add = 0;
   for (int i = 0; i < wv; ++i) add += wave_tot[i];
-  (void)nw;
+  if (threadIdx.x == blockDim.x - 1) wave_tot[16] = v + add;
   __syncthreads();
   return v + add;
 }
+
+struct JChain {  // a live chain between two rounds of the synchronisation
+  uint32_t p, cz, m, seg;
+};
 
 struct DcCarry {
   int32_t s[3];
   int32_t flag;  // a restart boundary lies inside (the sums restart there)
 };
 
-__global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(JpegBatch a) {
-  __shared__ hcir_jpeg_header sh;
-  __shared__ uint64_t sinfo[kHuffThreads];
-  __shared__ uint32_t cnt[kHuffThreads];
-  __shared__ uint32_t wave_tot[16];
-  __shared__ DcCarry carry[2][kHuffThreads];
-  const int tid = threadIdx.x, T = blockDim.x;
+// Re-lays an image's stream for the Huffman kernel: linear word g -> ilv[(g % wps) * nx + g / wps] (jpeg_word_addr),
+// through 32 x 32-word LDS tiles so that both the read (128 B per subsequence row) and the write (128 B = the same
+// word of 32 neighbouring subsequences) are whole lines.  Words behind the staged stream read as 1-bits.
+__global__ __launch_bounds__(256) void jpeg_interleave_kernel(JpegBatch a) {
+  __shared__ uint32_t tile[32][33];
+  const int64_t img = blockIdx.y;
+  const hcir_jpeg_header* h = hdr_of(a, img);
+  if (h->width == 0 || h->stream_bits == 0) return;
+  JSubseq q;
+  jpeg_subseq(h->stream_bits, h->stream_words, (uint32_t)a.huff_threads, q);
+  const uint32_t tiles_j = (q.wps + 31) / 32, tiles_t = (q.nx + 31) / 32;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(a.blob + h->stage_offset);
+  uint32_t* dst = a.ilv + img * a.ilv_stride;
+  const uint32_t x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+  for (uint32_t tl = blockIdx.x; tl < tiles_j * tiles_t; tl += gridDim.x) {
+    const uint32_t t0 = (tl / tiles_j) * 32, j0 = (tl % tiles_j) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t r = y0 + 8 * k, t = t0 + r, j = j0 + x;
+      const uint64_t g = (uint64_t)t * q.wps + j;
+      tile[r][x] = (t < q.nx && j < q.wps && g < h->stream_words) ? src[g] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t r = y0 + 8 * k, j = j0 + r, t = t0 + x;
+      if (j < q.wps && t < q.nx) dst[(uint64_t)j * q.nx + t] = tile[x][r];
+    }
+    __syncthreads();
+  }
+}
+
+// kT threads = subsequences per image.  1024: two workgroups per CU, shortest subsequences (small batches: latency);
+// 512: four per CU (33 KB of LDS each), so a batch of ~1000 images is resident at once and one image's serial tail
+// (the few chains that take many rounds to merge) runs under the others' bulk phases.
+template <int kT, bool kFast>
+__global__ __launch_bounds__(kT, 8) void jpeg_huffman_kernel(JpegBatch a) {
+  // LDS: the header up to its Huffman tables (geometry, selectors, quantisation) and the LOOKUP part of the four
+  // tables; the canonical ranges behind them stay in global memory (only tables whose long codes overflow the
+  // second lookup level ever read them)
+  constexpr int kHeadWords = (int)(offsetof(hcir_jpeg_header, huff) / 4);
+  constexpr int kLutWords = (int)(sizeof(hcir_jpeg_lut) / 4);
+  __shared__ uint32_t sh_raw[kHeadWords];
+  __shared__ hcir_jpeg_lut luts[4];
+  __shared__ uint64_t sinfo[kT];
+  __shared__ uint32_t cnt[kT];
+  __shared__ uint32_t wave_tot[17];
+  __shared__ DcCarry wave_carry[16];
+  __shared__ JChain queue[kT / 4];
+  const hcir_jpeg_header& sh = *reinterpret_cast<const hcir_jpeg_header*>(sh_raw);  // fields in front of .huff only
+  const int tid = threadIdx.x, T = kT;
   const int64_t img = blockIdx.x;
-  {  // header -> LDS (4-byte pieces; sizeof is a multiple of 8)
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(hdr_of(a, img));
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&sh);
-    for (int i = tid; i < (int)(sizeof(hcir_jpeg_header) / 4); i += T) dst[i] = src[i];
+  {
+    const hcir_jpeg_header* gh = hdr_of(a, img);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gh);
+    for (int i = tid; i < kHeadWords; i += T) sh_raw[i] = src[i];
+    for (int i = tid; i < 4 * kLutWords; i += T)
+      reinterpret_cast<uint32_t*>(&luts[i / kLutWords])[i % kLutWords] =
+          reinterpret_cast<const uint32_t*>(&gh->huff[i / kLutWords].lut)[i % kLutWords];
   }
   __syncthreads();
   JWin w;
   jpeg_window(sh, a.win_h, a.win_w, w);
+  if (tid == 0) {
+    JGeom* g = a.geom + img;
+    g->w = w;
+    int32_t off = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      JPlane pl;
+      jpeg_plane(sh, w, c < sh.ncomp ? c : 0, pl);
+      g->pl[c] = pl;
+      g->plane_off[c] = off;
+      off += pl.pitch * pl.rows;
+    }
+    g->ncomp = sh.ncomp;
+    g->width = sh.width;
+    g->height = sh.height;
+    g->rounds = 0;
+  }
+#ifdef HCIR_JPEG_STAMPS
+#define JSTAMP(i) if (tid == 0) a.geom[img].stamp[i] = (uint32_t)__builtin_amdgcn_s_memrealtime()
+#else
+#define JSTAMP(i)
+#endif
+  JSTAMP(0);
   if (w.last_mcu < 0 || sh.stream_bits == 0) {  // window off the image (all padding) / empty scan
     if (tid == 0 && a.status) a.status[img] = w.last_mcu < 0 ? HCIR_OK : HCIR_ERR_INVALID;
     return;
   }
+  JSubseq sq;
+  jpeg_subseq(sh.stream_bits, sh.stream_words, (uint32_t)T, sq);
   JStream J;
-  J.words = reinterpret_cast<const uint32_t*>(a.blob + sh.stage_offset);
-  J.seg_start = J.words + (((size_t)sh.stream_words * 4 + 15) / 16) * 4;
+  J.words = a.ilv + img * a.ilv_stride;
+  J.wps = sq.wps;
+  J.nx = sq.nx;
+  J.seg_start = reinterpret_cast<const uint32_t*>(a.blob + sh.stage_offset) + (((size_t)sh.stream_words * 4 + 15) / 16) * 4;
   J.nseg = (uint32_t)sh.nsegments;
   J.stream_bits = sh.stream_bits;
   J.bpm = (uint32_t)sh.blocks_per_mcu;
   jpeg_stream_tables(sh, J);
-  uint32_t S = (J.stream_bits + (uint32_t)T - 1) / (uint32_t)T;
-  S = (S + 31) & ~31u;
-  if (S < 128) S = 128;
-  const uint32_t nact = (J.stream_bits + S - 1) / S;
+  J.luts = luts;
+  J.tabs = hdr_of(a, img)->huff;
+  const uint32_t S = sq.bits, nact = sq.nact;
   auto limit = [&](uint32_t m) {
     const uint64_t l = (uint64_t)(m + 1) * S;
     return (uint32_t)(l < J.stream_bits ? l : J.stream_bits);
@@ -116,23 +205,50 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(JpegBatch a)
   // ---- phase 0: speculative decode ----
   if ((uint32_t)tid < nact) {
     jpeg_state_at(J, (uint32_t)tid * S, 0, 0, st);
-    cnt[tid] = jpeg_decode_span(J, st, limit((uint32_t)tid), null_sink);
+    cnt[tid] = jpeg_decode_span<kFast>(J, st, limit((uint32_t)tid), null_sink);
     sinfo[tid] = jpeg_state_key(st);
   }
-  // ---- synchronisation: every active thread verifies the subsequences behind its own ----
-  bool done = (uint32_t)tid >= nact;
-  for (uint32_t k = 1; k <= nact; ++k) {  // bounded: thread 0 alone needs at most nact - 1 iterations
-    const uint32_t m = (uint32_t)tid + k;
-    if (!done && m >= nact) done = true;
-    if (!__syncthreads_or(!done)) break;  // also orders the previous iteration's LDS writes before these reads
-    if (!done) {
-      const uint32_t nb = jpeg_decode_span(J, st, limit(m), null_sink);
+  JSTAMP(1);
+  // ---- synchronisation: every chain verifies the subsequences behind its own, one per round, in lock step ----
+  // Round 1 runs in place (every thread decodes the subsequence behind its own).  Most chains have merged by
+  // then; the survivors are few and scattered over the waves, so from round 2 on they are COMPACTED into an LDS
+  // queue and the first `live` threads take one each: a round costs the issue slots of ceil(live / 64) waves, not
+  // of every wave that still holds one unfinished lane.  One subsequence per live chain per round, so the chains
+  // through a subsequence still arrive in order of decreasing origin (the last writer is the verified one).
+  uint32_t m_next = (uint32_t)tid + 1;
+  bool live = m_next < nact;
+  __syncthreads();
+  for (uint32_t round = 1; round <= nact; ++round) {  // bounded: thread 0's chain alone ends after nact - 1 rounds
+    if (live) {
+      const uint32_t nb = jpeg_decode_span<kFast>(J, st, limit(m_next), null_sink);
       const uint64_t key = jpeg_state_key(st);
-      if (sinfo[m] == key) done = true; else sinfo[m] = key;
-      cnt[m] = nb;  // the chain with the smallest origin through m decodes it last, and it is the verified one
+      if (sinfo[m_next] == key) live = false; else sinfo[m_next] = key;
+      cnt[m_next] = nb;  // the chain with the smallest origin through m decodes it last, and it is the verified one
+      if (++m_next >= nact) live = false;
     }
+    const uint32_t incl = block_inclusive_scan(live ? 1u : 0u, wave_tot);  // two barriers: orders the LDS traffic
+    const uint32_t nlive = wave_tot[16];
+    if (round == 1) { JSTAMP(2); }
+    if (tid == 0) a.geom[img].rounds = (int32_t)round;
+    if (nlive == 0) break;
+    if (nlive <= (uint32_t)(kT / 4)) {  // few survivors: pack them into the first waves (else carry on in place)
+      if (live) queue[incl - 1] = JChain{st.p, (st.c << 8) | st.z, m_next, st.seg};
+      __syncthreads();
+      live = (uint32_t)tid < nlive;
+      if (live) {
+        const JChain q = queue[tid];
+        st.p = q.p;
+        st.c = q.cz >> 8;
+        st.z = q.cz & 255u;
+        st.seg = q.seg;
+        st.seg_end = q.seg >= J.nseg ? J.stream_bits : J.seg_start[q.seg + 1];
+        m_next = q.m;
+      }
+    }
+    __syncthreads();
   }
   __syncthreads();
+  JSTAMP(3);
   // ---- first block of every subsequence ----
   const uint32_t mine = (uint32_t)tid < nact ? cnt[tid] : 0;
   const uint32_t incl = block_inclusive_scan(mine, wave_tot);
@@ -150,11 +266,12 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(JpegBatch a)
       const uint64_t key = sinfo[tid - 1];
       jpeg_state_at(J, (uint32_t)(key >> 16), (uint32_t)(key >> 8) & 255u, (uint32_t)key & 255u, st);
     }
-    JWriteSink sink{&sh, &w, dcdiff, coef, 0, last_block, -1};
+    JWriteSink sink{&sh, &w, dcdiff, coef, 0, last_block, -1, 0, 0, 0};
     sink.begin(first);
-    jpeg_decode_span(J, st, limit((uint32_t)tid), sink);
+    jpeg_decode_span<kFast>(J, st, limit((uint32_t)tid), sink);
   }
   __syncthreads();  // this workgroup's dcdiff stores are visible to its own threads behind the barrier
+  JSTAMP(4);
   // ---- DC prediction: segmented prefix sums over the MCUs [0, last_mcu] ----
   const uint32_t nmcu = (uint32_t)w.last_mcu + 1, bpm = (uint32_t)sh.blocks_per_mcu;
   const uint32_t chunk = (nmcu + (uint32_t)T - 1) / (uint32_t)T;
@@ -165,29 +282,32 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(JpegBatch a)
     if (m % ri == 0) c = DcCarry{{0, 0, 0}, 1};
     for (uint32_t k = 0; k < bpm; ++k) c.s[sh.blk_comp[k]] += dcdiff[m * bpm + k];
   }
-  carry[0][tid] = c;
+  // segmented inclusive scan of the chunk sums: shuffles inside a wave, the waves' totals through LDS
+  auto combine = [](const DcCarry& left, const DcCarry& right) {
+    if (right.flag) return right;
+    return DcCarry{{left.s[0] + right.s[0], left.s[1] + right.s[1], left.s[2] + right.s[2]}, left.flag};
+  };
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    DcCarry u;
+    u.s[0] = __shfl_up(c.s[0], o);
+    u.s[1] = __shfl_up(c.s[1], o);
+    u.s[2] = __shfl_up(c.s[2], o);
+    u.flag = __shfl_up(c.flag, o);
+    if (lane >= o) c = combine(u, c);
+  }
+  if (lane == 63) wave_carry[wv] = c;
   __syncthreads();
-  int cur = 0;
-  for (int o = 1; o < T; o <<= 1) {  // Hillis-Steele with the segmented combine
-    DcCarry v = carry[cur][tid];
-    if (tid >= o && !v.flag) {
-      const DcCarry u = carry[cur][tid - o];
-      v.s[0] += u.s[0];
-      v.s[1] += u.s[1];
-      v.s[2] += u.s[2];
-      v.flag = u.flag;
-    }
-    carry[cur ^ 1][tid] = v;
-    cur ^= 1;
-    __syncthreads();
-  }
-  int32_t pred[3] = {0, 0, 0};
-  if (tid > 0) {
-    const DcCarry u = carry[cur][tid - 1];
-    pred[0] = u.s[0];
-    pred[1] = u.s[1];
-    pred[2] = u.s[2];
-  }
+  DcCarry before{{0, 0, 0}, 0};  // everything in front of this wave
+  for (int i = 0; i < wv; ++i) before = combine(before, wave_carry[i]);
+  DcCarry excl;                  // everything in front of this thread
+  excl.s[0] = __shfl_up(c.s[0], 1);
+  excl.s[1] = __shfl_up(c.s[1], 1);
+  excl.s[2] = __shfl_up(c.s[2], 1);
+  excl.flag = __shfl_up(c.flag, 1);
+  excl = lane == 0 ? before : combine(before, excl);
+  int32_t pred[3] = {excl.s[0], excl.s[1], excl.s[2]};
   for (uint32_t m = m0; m < m1; ++m) {
     if (m % ri == 0) pred[0] = pred[1] = pred[2] = 0;
     for (uint32_t k = 0; k < bpm; ++k) {
@@ -197,32 +317,38 @@ __global__ __launch_bounds__(kHuffThreads) void jpeg_huffman_kernel(JpegBatch a)
       if (slot >= 0) coef[(int64_t)slot * 64] = (int16_t)pred[ci];
     }
   }
+  JSTAMP(5);
 }
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegBatch a) {
-  __shared__ hcir_jpeg_header sh;  // geometry + quantisation tables (the Huffman tables ride along: one copy loop)
+  __shared__ uint16_t quant[3][64];
+  __shared__ JGeom g;
+  __shared__ uint8_t blk_comp[12];
+  __shared__ int32_t hs[3], vs[3], bpm;
   const int64_t img = blockIdx.y;
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(hdr_of(a, img));
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&sh);
-    constexpr int kWords = (int)(offsetof(hcir_jpeg_header, huff) / 4);
-    for (int i = threadIdx.x; i < kWords; i += blockDim.x) dst[i] = src[i];
+  const hcir_jpeg_header* h = hdr_of(a, img);
+  if (threadIdx.x < 96) reinterpret_cast<uint32_t*>(&quant[0][0])[threadIdx.x] = reinterpret_cast<const uint32_t*>(&h->quant[0][0])[threadIdx.x];
+  if (threadIdx.x >= 128 && threadIdx.x < 128 + sizeof(JGeom) / 4)
+    reinterpret_cast<uint32_t*>(&g)[threadIdx.x - 128] = reinterpret_cast<const uint32_t*>(a.geom + img)[threadIdx.x - 128];
+  if (threadIdx.x >= 96 && threadIdx.x < 108) blk_comp[threadIdx.x - 96] = h->blk_comp[threadIdx.x - 96];
+  if (threadIdx.x >= 108 && threadIdx.x < 111) {
+    hs[threadIdx.x - 108] = h->hs[threadIdx.x - 108];
+    vs[threadIdx.x - 108] = h->vs[threadIdx.x - 108];
   }
+  if (threadIdx.x == 111) bpm = h->blocks_per_mcu;
   __syncthreads();
-  JWin w;
-  jpeg_window(sh, a.win_h, a.win_w, w);
   const int32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= w.wblocks) return;
-  int ci;
-  int32_t sx, sy;
-  jpeg_block_place(sh, w, slot, ci, sx, sy);
-  JPlane pl;
-  uint8_t* plane = a.planes + img * a.plane_stride;
-  for (int c = 0; c < ci; ++c) {
-    jpeg_plane(sh, w, c, pl);
-    plane += (int64_t)pl.pitch * pl.rows;
-  }
-  jpeg_plane(sh, w, ci, pl);
+  if (slot >= g.w.wblocks) return;
+  // where the block lands (jpeg_block_place on the LDS copies)
+  const int32_t wm = slot / bpm, blk = slot - wm * bpm;
+  const int32_t ry = wm / g.w.nmx, rx = wm - ry * g.w.nmx;
+  const int ci = blk_comp[blk];
+  int32_t first = 0;
+  for (int c = 0; c < ci; ++c) first += hs[c] * vs[c];
+  const int32_t k = blk - first, by = k / hs[ci], bx = k - by * hs[ci];
+  const int32_t sx = (rx * hs[ci] + bx) * 8, sy = (ry * vs[ci] + by) * 8;
+  const int32_t pitch = g.pl[ci].pitch;
+  uint8_t* plane = a.planes + img * a.plane_stride + g.plane_off[ci];
   // 64 coefficients: eight 16-byte loads
   int16_t cf[64];
   const uint4* src = reinterpret_cast<const uint4*>(a.coef + img * a.coef_stride + (int64_t)slot * 64);
@@ -237,65 +363,80 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegBatch a) {
     }
   }
   uint8_t px[64];
-  jpeg_idct_block(cf, sh.quant[ci], px, 8);
-  uint8_t* dst = plane + (int64_t)sy * pl.pitch + sx;
+  jpeg_idct_block(cf, quant[ci], px, 8);
+  uint8_t* dst = plane + (int64_t)sy * pitch + sx;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     uint2 v;
     v.x = px[r * 8] | (px[r * 8 + 1] << 8) | (px[r * 8 + 2] << 16) | ((uint32_t)px[r * 8 + 3] << 24);
     v.y = px[r * 8 + 4] | (px[r * 8 + 5] << 8) | (px[r * 8 + 6] << 16) | ((uint32_t)px[r * 8 + 7] << 24);
-    *reinterpret_cast<uint2*>(dst + (int64_t)r * pl.pitch) = v;  // sx and pitch are multiples of 8
+    *reinterpret_cast<uint2*>(dst + (int64_t)r * pitch) = v;  // sx and pitch are multiples of 8
   }
 }
 
+// kPix output pixels of one row per thread (4: twelve contiguous bytes leave as three dword stores; needs win_w % 4 == 0)
+template <int kPix>
 __global__ __launch_bounds__(256) void jpeg_color_kernel(JpegBatch a) {
-  __shared__ hcir_jpeg_header sh;
+  __shared__ JGeom g;
   const int64_t img = blockIdx.y;
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(hdr_of(a, img));
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&sh);
-    constexpr int kWords = (int)(offsetof(hcir_jpeg_header, quant) / 4);
-    for (int i = threadIdx.x; i < kWords; i += blockDim.x) dst[i] = src[i];
-  }
+  if (threadIdx.x < sizeof(JGeom) / 4)
+    reinterpret_cast<uint32_t*>(&g)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.geom + img)[threadIdx.x];
   __syncthreads();
-  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.win_h * a.win_w) return;
-  JWin w;
-  jpeg_window(sh, a.win_h, a.win_w, w);
-  const int32_t oy = p / a.win_w, ox = p - oy * a.win_w;
-  const int32_t x = w.x0 + ox, y = w.y0 + oy;
-  uint8_t rgb[3] = {0, 0, 0};
-  if (x >= 0 && y >= 0 && x < sh.width && y < sh.height) {
-    const uint8_t* plane = a.planes + img * a.plane_stride;
-    JPlane pl;
-    jpeg_plane(sh, w, 0, pl);
-    const int32_t yy = jpeg_upsampled(plane, pl.pitch, pl.px0, pl.py0, pl.dw, pl.dh, pl.fx, pl.fy, x, y);
-    if (sh.ncomp == 1) {
-      rgb[0] = rgb[1] = rgb[2] = (uint8_t)yy;
-    } else {
-      plane += (int64_t)pl.pitch * pl.rows;
-      jpeg_plane(sh, w, 1, pl);
-      const int32_t cb = jpeg_upsampled(plane, pl.pitch, pl.px0, pl.py0, pl.dw, pl.dh, pl.fx, pl.fy, x, y);
-      plane += (int64_t)pl.pitch * pl.rows;
-      jpeg_plane(sh, w, 2, pl);
-      const int32_t cr = jpeg_upsampled(plane, pl.pitch, pl.px0, pl.py0, pl.dw, pl.dh, pl.fx, pl.fy, x, y);
-      jpeg_ycc_rgb(yy, cb, cr, rgb);
+  const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t per_row = a.win_w / kPix;
+  if (t >= a.win_h * per_row) return;
+  const int32_t oy = t / per_row, ox0 = (t - oy * per_row) * kPix;
+  const int32_t y = g.w.y0 + oy;
+  const uint8_t* base = a.planes + img * a.plane_stride;
+  uint8_t rgb[kPix * 3];
+#pragma unroll
+  for (int i = 0; i < kPix; ++i) {
+    const int32_t x = g.w.x0 + ox0 + i;
+    uint8_t* o = rgb + 3 * i;
+    o[0] = o[1] = o[2] = 0;
+    if (x >= 0 && y >= 0 && x < g.width && y < g.height) {
+      const JPlane& p0 = g.pl[0];
+      const int32_t yy = jpeg_upsampled(base + g.plane_off[0], p0.pitch, p0.px0, p0.py0, p0.dw, p0.dh, p0.fx, p0.fy, x, y);
+      if (g.ncomp == 1) {
+        o[0] = o[1] = o[2] = (uint8_t)yy;
+      } else {
+        const JPlane& p1 = g.pl[1];
+        const JPlane& p2 = g.pl[2];
+        const int32_t cb = jpeg_upsampled(base + g.plane_off[1], p1.pitch, p1.px0, p1.py0, p1.dw, p1.dh, p1.fx, p1.fy, x, y);
+        const int32_t cr = jpeg_upsampled(base + g.plane_off[2], p2.pitch, p2.px0, p2.py0, p2.dw, p2.dh, p2.fx, p2.fy, x, y);
+        jpeg_ycc_rgb(yy, cb, cr, o);
+      }
     }
   }
-  uint8_t* o = a.out + (img * (int64_t)a.win_h * a.win_w + p) * 3;
-  o[0] = rgb[0];
-  o[1] = rgb[1];
-  o[2] = rgb[2];
+  uint8_t* o = a.out + (img * (int64_t)a.win_h * a.win_w + (int64_t)oy * a.win_w + ox0) * 3;
+  if (kPix == 4) {
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(o);  // (pixel index multiple of 4) * 3 bytes: 4-byte aligned
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o32[j] = rgb[4 * j] | (rgb[4 * j + 1] << 8) | (rgb[4 * j + 2] << 16) | ((uint32_t)rgb[4 * j + 3] << 24);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPix * 3; ++j) o[j] = rgb[j];
+  }
 }
 
 struct Plan {
-  int64_t coef_stride, dc_stride, plane_stride;  // elements per image (int16, int16, uint8), 128-byte multiples
-  int32_t max_wblocks;
+  int64_t coef_stride, dc_stride, plane_stride, ilv_stride;  // elements per image (int16, int16, uint8, uint32)
+  int32_t max_wblocks, huff_threads;
+  bool fast;  // every table in use of every image resolves its long codes in the second lookup level
+  int64_t max_words;
+  size_t bytes(int64_t b) const {
+    return (size_t)(b * (coef_stride * 2 + dc_stride * 2 + plane_stride + ilv_stride * 4 + (int64_t)sizeof(JGeom))) + 1024;
+  }
 };
 
 int make_plan(const hcir_jpeg_header* hdrs, int64_t b, int32_t win_h, int32_t win_w, Plan* p) {
-  int64_t mc = 0, md = 0, mp = 0;
+  int64_t mc = 0, md = 0, mp = 0, mi = 0, mwords = 0;
   int32_t mw = 0;
+  // 512 threads: four workgroups per CU, a batch of ~1000 images resident at once; small batches take the shorter
+  // subsequences of 1024 threads (latency)
+  p->huff_threads = b >= 384 ? 512 : 1024;
+  p->fast = true;
   for (int64_t i = 0; i < b; ++i) {
     const hcir_jpeg_header& h = hdrs[i];
     if (h.width == 0) continue;  // placeholder of a file the stager rejected: skipped, its window stays zero
@@ -305,6 +446,13 @@ int make_plan(const hcir_jpeg_header* hdrs, int64_t b, int32_t win_h, int32_t wi
     JWin w;
     jpeg_window(h, win_h, win_w, w);
     if (w.last_mcu < 0) continue;
+    JStream js;
+    jpeg_stream_tables(h, js);
+    p->fast = p->fast && js.fast2;
+    JSubseq q;
+    jpeg_subseq(h.stream_bits, h.stream_words, (uint32_t)p->huff_threads, q);
+    mi = (int64_t)q.nx * q.wps > mi ? (int64_t)q.nx * q.wps : mi;
+    mwords = h.stream_words > mwords ? h.stream_words : mwords;
     mw = w.wblocks > mw ? w.wblocks : mw;
     mc = (int64_t)w.wblocks * 64 > mc ? (int64_t)w.wblocks * 64 : mc;
     const int64_t nd = ((int64_t)w.last_mcu + 1) * h.blocks_per_mcu;
@@ -320,7 +468,9 @@ int make_plan(const hcir_jpeg_header* hdrs, int64_t b, int32_t win_h, int32_t wi
   p->coef_stride = (mc + 63) / 64 * 64;
   p->dc_stride = (md + 63) / 64 * 64;
   p->plane_stride = (mp + 127) / 128 * 128;
+  p->ilv_stride = (mi + 63) / 64 * 64;
   p->max_wblocks = mw;
+  p->max_words = mwords;
   return HCIR_OK;
 }
 
@@ -347,7 +497,7 @@ extern "C" int hcir_jpeg_stage(const uint8_t* file, size_t nbytes, hcir_jpeg_hea
 extern "C" size_t hcir_jpeg_workspace_bytes(const hcir_jpeg_header* hdrs_host, int64_t b, int32_t win_h, int32_t win_w) {
   Plan p;
   if (!hdrs_host || b <= 0 || win_h <= 0 || win_w <= 0 || make_plan(hdrs_host, b, win_h, win_w, &p) != HCIR_OK) return 0;
-  return (size_t)(b * (p.coef_stride * 2 + p.dc_stride * 2 + p.plane_stride)) + 256;
+  return p.bytes(b);
 }
 
 extern "C" int hcir_jpeg_decode_window_u8(const void* blob_dev, const hcir_jpeg_header* hdrs_host, int64_t b,
@@ -360,7 +510,7 @@ extern "C" int hcir_jpeg_decode_window_u8(const void* blob_dev, const hcir_jpeg_
   Plan p;
   const int rc = make_plan(hdrs_host, b, win_h, win_w, &p);
   if (rc != HCIR_OK) return rc;
-  const size_t need = (size_t)(b * (p.coef_stride * 2 + p.dc_stride * 2 + p.plane_stride)) + 256;
+  const size_t need = p.bytes(b);
   if (workspace_bytes < need) return HCIR_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   JpegBatch a{};
@@ -371,22 +521,41 @@ extern "C" int hcir_jpeg_decode_window_u8(const void* blob_dev, const hcir_jpeg_
   a.out = out;
   a.status = status_dev;
   uint8_t* ws = reinterpret_cast<uint8_t*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  a.coef = reinterpret_cast<int16_t*>(ws);
+  a.geom = reinterpret_cast<JGeom*>(ws);  // first: tools/diag_jpeg.py reads the records back
+  a.coef = reinterpret_cast<int16_t*>(ws + (((size_t)b * sizeof(JGeom) + 255) & ~(size_t)255));
   a.dcdiff = a.coef + b * p.coef_stride;
   a.planes = reinterpret_cast<uint8_t*>(a.dcdiff + b * p.dc_stride);
+  a.ilv = reinterpret_cast<uint32_t*>(((uintptr_t)(a.planes + b * p.plane_stride) + 255) & ~(uintptr_t)255);
+  a.ilv_stride = p.ilv_stride;
+  a.huff_threads = p.huff_threads;
   a.coef_stride = p.coef_stride;
   a.dc_stride = p.dc_stride;
   a.plane_stride = p.plane_stride;
   // AC coefficients are stored sparsely: the buffer starts as zeros
   if (p.coef_stride && hipMemsetAsync(a.coef, 0, (size_t)(b * p.coef_stride * 2), st) != hipSuccess) return HCIR_ERR_LAUNCH;
-  hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((unsigned)b), dim3(kHuffThreads), 0, st, a);
+  if (p.max_words > 0) {
+    const int64_t tiles = hcir_cdiv(p.max_words, 1024) + 64;
+    hipLaunchKernelGGL(jpeg_interleave_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256), (unsigned)b), dim3(256), 0, st, a);
+    HCIR_LAUNCH_CHECK();
+  }
+  if (p.huff_threads == 512) {
+    if (p.fast) hipLaunchKernelGGL((jpeg_huffman_kernel<512, true>), dim3((unsigned)b), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((jpeg_huffman_kernel<512, false>), dim3((unsigned)b), dim3(512), 0, st, a);
+  } else {
+    if (p.fast) hipLaunchKernelGGL((jpeg_huffman_kernel<1024, true>), dim3((unsigned)b), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((jpeg_huffman_kernel<1024, false>), dim3((unsigned)b), dim3(1024), 0, st, a);
+  }
   HCIR_LAUNCH_CHECK();
   if (p.max_wblocks > 0) {
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)hcir_cdiv(p.max_wblocks, 256), (unsigned)b), dim3(256), 0, st, a);
     HCIR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(jpeg_color_kernel, dim3((unsigned)hcir_cdiv((int64_t)win_h * win_w, 256), (unsigned)b), dim3(256), 0,
-                     st, a);
+  if (win_w % 4 == 0)
+    hipLaunchKernelGGL(jpeg_color_kernel<4>, dim3((unsigned)hcir_cdiv((int64_t)win_h * (win_w / 4), 256), (unsigned)b),
+                       dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(jpeg_color_kernel<1>, dim3((unsigned)hcir_cdiv((int64_t)win_h * win_w, 256), (unsigned)b), dim3(256),
+                       0, st, a);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

@@ -16,8 +16,10 @@
 
 #if defined(__HIPCC__)
 #define JHD __host__ __device__ __forceinline__
+#define JHD_COLD __host__ __device__ __attribute__((noinline))
 #else
 #define JHD inline
+#define JHD_COLD inline
 #endif
 
 // zigzag index -> natural (row-major) index; 16 extra entries catch a run that overshoots 63 on a
@@ -43,28 +45,91 @@ struct JState {
 JHD uint64_t jpeg_state_key(const JState& s) { return ((uint64_t)s.p << 16) | (s.c << 8) | s.z; }
 
 struct JStream {
-  const uint32_t* words;      // stream, word i holds bits [32 i, 32 i + 32), first bit in bit 31
+  // stream words, word g holding bits [32 g, 32 g + 32) with the first bit in bit 31, stored INTERLEAVED by
+  // subsequence: word j of subsequence t sits at words[j * nx + t] (jpeg_word_addr).  A wave's 64 lanes work on
+  // 64 neighbouring subsequences at about the same word offset j, so one wave load touches two or three 128-byte
+  // lines instead of 64 (with the stream stored linearly every lane pulled its own line through L1 for 4 useful
+  // bytes, and a CU's 1500 live lines no longer fitted any cache: phases ran 3-4x slower than their issue rate)
+  const uint32_t* words;
+  uint32_t wps, nx;           // words per subsequence, subsequences (incl. the padding tail) = row pitch
   const uint32_t* seg_start;  // [nseg + 1] start bit of every segment; [nseg] = stream_bits
   uint32_t nseg, stream_bits, bpm;
-  const hcir_jpeg_hufftab* tabs;  // the header's four tables
+  const hcir_jpeg_lut* luts;      // the four tables' lookup parts (LDS on the device)
+  const hcir_jpeg_hufftab* tabs;  // the header's full tables (range search for codes no lookup covers)
   uint32_t dc_sel, ac_sel;        // 4 bits per block of the MCU: which table (a register, not an indexed array)
+  uint32_t fast2;                 // every table in use resolves its long codes in the second lookup level
 };
 
 JHD void jpeg_stream_tables(const hcir_jpeg_header& h, JStream& J) {
-  J.tabs = h.huff;
   J.dc_sel = J.ac_sel = 0;
+  J.fast2 = 1;
   for (int i = 0; i < h.blocks_per_mcu && i < 8; ++i) {
     const int ci = h.blk_comp[i];
     J.dc_sel |= (uint32_t)h.dc_tab[ci] << (4 * i);
     J.ac_sel |= (uint32_t)h.ac_tab[ci] << (4 * i);
+    J.fast2 &= h.huff[h.dc_tab[ci]].lut.use2 & h.huff[h.ac_tab[ci]].lut.use2;
   }
 }
 
-JHD uint32_t jpeg_peek32(const uint32_t* w, uint32_t p) {
-  const uint32_t i = p >> 5, s = p & 31;
-  const uint64_t v = ((uint64_t)w[i] << 32) | w[i + 1];
+// subsequence geometry of a stream decoded by nthreads threads (one place, used by host and device alike)
+struct JSubseq {
+  uint32_t bits, wps, nact, nx;  // bits per subsequence (multiple of 32, >= 128), words, subsequences, row pitch
+};
+JHD void jpeg_subseq(uint32_t stream_bits, uint32_t stream_words, uint32_t nthreads, JSubseq& q) {
+  uint32_t S = (stream_bits + nthreads - 1) / nthreads;
+  S = (S + 31) & ~31u;
+  if (S < 128) S = 128;
+  q.bits = S;
+  q.wps = S / 32;
+  q.nact = (stream_bits + S - 1) / S;
+  q.nx = (stream_words + q.wps - 1) / q.wps;  // stream_words includes the padding words the reader may touch
+}
+
+JHD uint32_t jpeg_word_addr(const JStream& J, uint32_t g) {
+  const uint32_t t = g / J.wps;
+  return (g - t * J.wps) * J.nx + t;
+}
+
+JHD uint32_t jpeg_peek32(const JStream& J, uint32_t p) {
+  const uint32_t g = p >> 5, s = p & 31;
+  const uint64_t v = ((uint64_t)J.words[jpeg_word_addr(J, g)] << 32) | J.words[jpeg_word_addr(J, g + 1)];
   return (uint32_t)((v << s) >> 32);
 }
+
+// The hot loop's view of the stream: four consecutive words in registers.  Symbols are at most 31 bits, so the
+// word index advances by 0 or 1 per symbol.  Branch-free: every step selects the shifted or the unshifted window and
+// issues ONE load for the word three ahead (the same word again when the index did not move); the loaded word is
+// first needed a step later, so its latency stays off the symbol-to-symbol dependency chain.  The interleaved
+// address of that word is stepped (one row down, or up to the next subsequence's first row), not divided.  A
+// segment jump (the only way the index moves otherwise) calls load() again.
+struct JBitWin {
+  uint32_t wi, w0, w1, w2, w3;
+  uint32_t a3, r3;  // address of word wi + 3 and how many words are left below it in its subsequence
+  JHD void load(const JStream& J, uint32_t p) {
+    wi = p >> 5;
+    w0 = J.words[jpeg_word_addr(J, wi)];
+    w1 = J.words[jpeg_word_addr(J, wi + 1)];
+    w2 = J.words[jpeg_word_addr(J, wi + 2)];
+    const uint32_t t = (wi + 3) / J.wps, j = wi + 3 - t * J.wps;
+    a3 = j * J.nx + t;
+    r3 = J.wps - 1 - j;
+    w3 = J.words[a3];
+  }
+  JHD uint32_t peek(const JStream& J, uint32_t p) {
+    const uint32_t i = p >> 5;
+    const bool adv = i != wi;
+    w0 = adv ? w1 : w0;
+    w1 = adv ? w2 : w1;
+    w2 = adv ? w3 : w2;
+    const bool wrap = r3 == 0;
+    const uint32_t step = wrap ? 1u - (J.wps - 1) * J.nx : J.nx;  // unsigned wrap-around: one column right, wps - 1 rows up
+    a3 += adv ? step : 0u;
+    r3 = adv ? (wrap ? J.wps - 1 : r3 - 1) : r3;
+    w3 = J.words[a3];
+    wi = i;
+    return (uint32_t)(((((uint64_t)w0 << 32) | w1) << (p & 31)) >> 32);
+  }
+};
 
 JHD void jpeg_state_at(const JStream& J, uint32_t p, uint32_t c, uint32_t z, JState& s) {
   s.p = p;
@@ -85,25 +150,34 @@ JHD void jpeg_state_at(const JStream& J, uint32_t p, uint32_t c, uint32_t z, JSt
   }
 }
 
-// jdhuff.c: 8-bit lookahead, then the maxcode walk for longer codes.  bits32: next 32 stream bits, first in bit 31.
-JHD uint32_t jpeg_huff_symbol(const hcir_jpeg_hufftab* t, uint32_t bits32, uint32_t& nbits) {
-  const uint32_t look = t->look[bits32 >> 24];
-  if (look) {
-    nbits = look >> 8;
-    return look & 0xFF;
+// jdhuff.c's decode in table form.  bits32: next 32 stream bits, first in bit 31; lut: the table of the symbol that
+// comes next.  Returns the packed entry (include/hcir.h): codes of up to HCIR_JPEG_LOOK_BITS bits come out of one
+// lookup, longer ones out of a second one indexed by the distance of the 16-bit prefix from the first long code
+// (canonical codes pack the long ones at the top of the prefix space: 192 prefixes behind 11 bits for the standard
+// luminance AC table); a table whose long codes span more than HCIR_JPEG_LOOK2 prefixes falls back to the canonical
+// ranges in global memory (the length is the number of limits the prefix has reached).  An invalid prefix (only a
+// chain that is not synchronised sees one) decodes as a 16-bit code that advances the zigzag index by one.
+JHD uint32_t jpeg_huff_entry(const JStream& J, const hcir_jpeg_lut* lut, uint32_t bits32) {
+  uint32_t e = lut->look[bits32 >> (32 - HCIR_JPEG_LOOK_BITS)];
+  if (e == 0) {
+    const uint32_t v = bits32 >> 16;
+    if (lut->use2) {
+      e = lut->look2[v & (HCIR_JPEG_LOOK2 - 1)];  // use2: every long code lies in the top LOOK2 prefixes
+    } else {
+      const hcir_jpeg_hufftab* f = J.tabs + (uint32_t)(lut - J.luts);
+      uint32_t l = HCIR_JPEG_LOOK_BITS + 1;
+#pragma unroll
+      for (int k = HCIR_JPEG_LOOK_BITS + 1; k < 16; ++k) l += v >= f->limit[k] ? 1u : 0u;
+      if (v < f->limit[16]) {
+        const uint32_t sym = f->vals[(uint32_t)((int32_t)(v >> (16 - l)) + f->valoff[l]) & 255];
+        const uint32_t ssss = sym & 15, r = sym >> 4;
+        const uint32_t adv = !f->is_ac ? 1u : (ssss ? r + 1 : (r == 15 ? 16u : 0u));
+        e = (l + ssss) | (adv << 5) | (l << 10);
+      }
+    }
+    if (e == 0) e = 16u | (1u << 5) | (16u << 10);
   }
-  uint32_t l = 9;
-  int32_t code = (int32_t)(bits32 >> 23);
-  while (l <= 16 && code > t->maxcode[l]) {
-    code = (code << 1) | (int32_t)((bits32 >> (31 - l)) & 1);
-    ++l;
-  }
-  if (l > 16) {  // no such code: only a chain that is not (yet) synchronised gets here
-    nbits = 16;
-    return 0;
-  }
-  nbits = l;
-  return t->vals[(uint32_t)(code + t->valoff[l]) & 255];
+  return e;
 }
 
 JHD int32_t jpeg_extend(uint32_t v, uint32_t s) {  // HUFF_EXTEND
@@ -111,45 +185,37 @@ JHD int32_t jpeg_extend(uint32_t v, uint32_t s) {  // HUFF_EXTEND
 }
 
 struct JNullSink {
-  JHD void dc(int32_t) {}
-  JHD void ac(uint32_t, int32_t) {}
+  JHD void coef(uint32_t, uint32_t, uint32_t, uint32_t) {}
   JHD void block_done() {}
   JHD bool finished() const { return false; }
 };
 
-// Decodes every symbol that STARTS before bit `limit`; returns the number of blocks completed.  After each
-// symbol the state is canonicalised: fewer than 8 bits left in the segment and all of them 1 (the encoder's
-// padding — no Huffman code is all ones, ITU T.81 Annex C) or the segment exhausted => continue at the next
-// segment's first bit with (c, z) = (0, 0).
+// Decodes every symbol that STARTS before bit `limit`; returns the number of blocks completed.  One code path
+// for DC and AC symbols (a wave's lanes sit at different places of their blocks): the packed entry says how many
+// bits the symbol takes and how far the zigzag index moves; a sink that keeps coefficients gets the position, the
+// magnitude size and the bits to extract the value from.  The tables of the current block (DC / AC lookup of its
+// component) are two pointers refreshed when a block ends.  After each symbol the state is canonicalised: fewer
+// than 8 bits left in the segment and all of them 1 (the encoder's padding — no Huffman code is all ones, ITU
+// T.81 Annex C) or the segment exhausted => continue at the next segment's first bit with (c, z) = (0, 0).
 template <class Sink>
-JHD uint32_t jpeg_decode_span(const JStream& J, JState& s, uint32_t limit, Sink& sink) {
+JHD uint32_t jpeg_decode_span_generic(const JStream& J, JState& s, uint32_t limit, Sink& sink) {
   uint32_t nblk = 0;
+  JBitWin bw;
+  bw.load(J, s.p);
+  const hcir_jpeg_lut* lut_dc = J.luts + ((J.dc_sel >> (4 * s.c)) & 15);
+  const hcir_jpeg_lut* lut_ac = J.luts + ((J.ac_sel >> (4 * s.c)) & 15);
   while (s.p < limit && !sink.finished()) {
-    const uint32_t bits = jpeg_peek32(J.words, s.p);
-    uint32_t nb;
-    if (s.z == 0) {
-      const uint32_t ssss = jpeg_huff_symbol(J.tabs + ((J.dc_sel >> (4 * s.c)) & 15), bits, nb) & 15;
-      int32_t diff = 0;
-      if (ssss) diff = jpeg_extend((bits << nb) >> (32 - ssss), ssss);
-      s.p += nb + ssss;
-      sink.dc(diff);
-      s.z = 1;
-    } else {
-      const uint32_t rs = jpeg_huff_symbol(J.tabs + ((J.ac_sel >> (4 * s.c)) & 15), bits, nb);
-      const uint32_t r = rs >> 4, ssss = rs & 15;
-      if (ssss) {
-        s.z += r;
-        sink.ac(s.z, jpeg_extend((bits << nb) >> (32 - ssss), ssss));
-        s.z += 1;
-        s.p += nb + ssss;
-      } else {
-        s.z = (r == 15) ? s.z + 16 : 64;
-        s.p += nb;
-      }
-    }
+    const uint32_t bits = bw.peek(J, s.p);
+    const uint32_t e = jpeg_huff_entry(J, s.z == 0 ? lut_dc : lut_ac, bits);
+    const uint32_t len = e & 31, adv5 = (e >> 5) & 31;
+    if (adv5) sink.coef(s.z + adv5 - 1, len - (e >> 10), bits, e >> 10);  // position, magnitude size, bits, code length
+    s.z += adv5 ? adv5 : 64u;
+    s.p += len;
     if (s.z >= 64) {
       s.z = 0;
       s.c = (s.c + 1 == J.bpm) ? 0 : s.c + 1;
+      lut_dc = J.luts + ((J.dc_sel >> (4 * s.c)) & 15);
+      lut_ac = J.luts + ((J.ac_sel >> (4 * s.c)) & 15);
       ++nblk;
       sink.block_done();
     }
@@ -157,7 +223,7 @@ JHD uint32_t jpeg_decode_span(const JStream& J, JState& s, uint32_t limit, Sink&
       bool jump = s.p >= s.seg_end;
       if (!jump) {
         const uint32_t rem = s.seg_end - s.p;
-        jump = (jpeg_peek32(J.words, s.p) >> (32 - rem)) == ((1u << rem) - 1);
+        jump = (jpeg_peek32(J, s.p) >> (32 - rem)) == ((1u << rem) - 1);
       }
       if (jump) {
         s.seg += 1;
@@ -169,9 +235,80 @@ JHD uint32_t jpeg_decode_span(const JStream& J, JState& s, uint32_t limit, Sink&
           s.p = J.seg_start[s.seg];
           s.seg_end = J.seg_start[s.seg + 1];
         }
+        lut_dc = J.luts + (J.dc_sel & 15);
+        lut_ac = J.luts + (J.ac_sel & 15);
+        bw.load(J, s.p);
       }
     }
   }
+  return nblk;
+}
+
+// The same decode as the loop the kernels actually run (jpeg_decode_span_generic above is its plain statement and
+// the path of tables whose long codes do not fit the second lookup level).  What differs is only what costs issue
+// slots on a CU whose 32 waves share ONE scalar unit: no divergent branch per symbol.  (1) Both lookup levels are read
+// unconditionally and selected; (2) the end of a block is a handful of selects; (3) the padding test leaves the hot
+// loop: symbols are decoded up to seven bits before the segment's end (or the span limit), and only there the
+// canonicalisation is evaluated; (4) the block's table is picked by a bit-field extract of the selector word.
+// kFast is a COMPILE-time choice (the launcher knows every table of the batch): the kernels carry one loop, not both.
+template <bool kFast, class Sink>
+JHD uint32_t jpeg_decode_span(const JStream& J, JState& s, uint32_t limit, Sink& sink) {
+  if (!kFast) return jpeg_decode_span_generic(J, s, limit, sink);
+  uint32_t nblk = 0, p = s.p, z = s.z, c4 = 4 * s.c;
+  const uint32_t bpm4 = 4 * J.bpm;
+  JBitWin bw;
+  bw.load(J, p);
+  auto step = [&]() {
+    const uint32_t bits = bw.peek(J, p);
+    const hcir_jpeg_lut* lut = J.luts + (((z == 0 ? J.dc_sel : J.ac_sel) >> c4) & 15);
+    const uint32_t e1 = lut->look[bits >> (32 - HCIR_JPEG_LOOK_BITS)];
+    const uint32_t e2 = lut->look2[(bits >> 16) & (HCIR_JPEG_LOOK2 - 1)];
+    uint32_t e = e1 ? e1 : e2;
+    e = e ? e : (16u | (1u << 5) | (16u << 10));
+    const uint32_t len = e & 31, adv5 = (e >> 5) & 31;
+    if (adv5) sink.coef(z + adv5 - 1, len - (e >> 10), bits, e >> 10);
+    z += adv5 ? adv5 : 64u;
+    p += len;
+    const bool done = z >= 64;
+    const uint32_t c4n = c4 + 4 == bpm4 ? 0 : c4 + 4;
+    z = done ? 0 : z;
+    c4 = done ? c4n : c4;
+    nblk += done ? 1u : 0u;
+    if (done) sink.block_done();
+  };
+  for (;;) {
+    const uint32_t safe = s.seg_end >= 7 ? s.seg_end - 7 : 0;  // p + 8 > seg_end  <=>  p >= seg_end - 7
+    const uint32_t eff = limit < safe ? limit : safe;
+    while (p < eff && !sink.finished()) step();
+    if (p + 8 > s.seg_end && s.seg < J.nseg) {  // the segment's last bits: padding?
+      bool jump = p >= s.seg_end;
+      if (!jump) {
+        const uint32_t rem = s.seg_end - p;
+        jump = (jpeg_peek32(J, p) >> (32 - rem)) == ((1u << rem) - 1);
+      }
+      if (jump) {
+        s.seg += 1;
+        c4 = z = 0;
+        if (s.seg >= J.nseg) {
+          s.seg = J.nseg;
+          p = s.seg_end = J.stream_bits;
+        } else {
+          p = J.seg_start[s.seg];
+          s.seg_end = J.seg_start[s.seg + 1];
+        }
+        bw.load(J, p);
+        continue;
+      }
+      if (p < limit && !sink.finished()) {  // real symbols in the last seven bits
+        step();
+        continue;
+      }
+    }
+    break;
+  }
+  s.p = p;
+  s.z = z;
+  s.c = c4 >> 2;
   return nblk;
 }
 
@@ -315,23 +452,42 @@ struct JWriteSink {
   const hcir_jpeg_header* h;
   const JWin* w;
   int16_t* dcdiff;  // [last_block + 1] in scan order
-  int16_t* coef;    // [wblocks][64] natural order, zero-filled by the caller
+  int16_t* coefs;   // [wblocks][64] natural order, zero-filled by the caller
   uint32_t b;       // scan-order index of the block being decoded
   uint32_t last_block;
-  int32_t slot;
+  int32_t slot;     // its place in the window buffer, -1 outside
+  int32_t blk, mx, my;  // block inside the MCU, MCU column / row: stepped, not divided, from block to block
+  JHD void place() {
+    const int32_t ry = my - w->my0, rx = mx - w->mx0;
+    slot = (b <= last_block && ry >= 0 && ry < w->nmy && rx >= 0 && rx < w->nmx)
+               ? (ry * w->nmx + rx) * h->blocks_per_mcu + blk : -1;
+  }
   JHD void begin(uint32_t b0) {
     b = b0;
-    slot = b <= last_block ? jpeg_window_slot(*h, *w, b) : -1;
+    const uint32_t mcu = b0 / (uint32_t)h->blocks_per_mcu;
+    blk = (int32_t)(b0 - mcu * (uint32_t)h->blocks_per_mcu);
+    my = (int32_t)(mcu / (uint32_t)h->mcus_x);
+    mx = (int32_t)(mcu - (uint32_t)my * (uint32_t)h->mcus_x);
+    place();
   }
-  JHD void dc(int32_t d) {
-    if (b <= last_block) dcdiff[b] = (int16_t)d;
-  }
-  JHD void ac(uint32_t z, int32_t v) {
-    if (slot >= 0) coef[slot * 64 + jpeg_natural((int)z)] = (int16_t)v;
+  JHD void coef(uint32_t z, uint32_t ssss, uint32_t bits, uint32_t nb) {
+    const int32_t v = ssss ? jpeg_extend((bits << nb) >> (32 - ssss), ssss) : 0;
+    if (z == 0) {
+      if (b <= last_block) dcdiff[b] = (int16_t)v;
+    } else if (slot >= 0 && ssss) {  // ssss == 0 behind the DC symbol is ZRL: nothing to store
+      coefs[slot * 64 + jpeg_natural((int)z)] = (int16_t)v;
+    }
   }
   JHD void block_done() {
     ++b;
-    slot = b <= last_block ? jpeg_window_slot(*h, *w, b) : -1;
+    if (++blk == h->blocks_per_mcu) {
+      blk = 0;
+      if (++mx == h->mcus_x) {
+        mx = 0;
+        ++my;
+      }
+    }
+    place();
   }
   JHD bool finished() const { return b > last_block; }
 };

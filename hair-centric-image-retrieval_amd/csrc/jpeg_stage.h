@@ -2,7 +2,7 @@
 // so that the CPU tests compile the very same parser (tests/jpeg_emul.cpp).
 //
 // What the reference's decoders do here is libjpeg's jdmarker.c (read_markers, get_sof, get_dht, get_dqt,
-// get_dri, get_sos) and jdhuff.c's jpeg_make_d_derived_tbl; behind HP/utils/dataloader.py:28-31
+// get_dri, get_sos) and jdhuff.c's jpeg_make_d_derived_tbl (here: a 10-bit lookahead table and the canonical ranges); behind HP/utils/dataloader.py:28-31
 // (torchvision.io.decode_image) and src/models/hair_encoder.py:108 (PIL).  The staging copy replaces the
 // byte-at-a-time unstuffing of jdhuff.c's fill_bit_buffer: one pass that drops the zero after every FF and the
 // RSTn markers, records where every restart segment starts, and packs the bytes into 32-bit words whose bit 31
@@ -23,9 +23,17 @@ static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// jpeg_make_d_derived_tbl: canonical codes from BITS / HUFFVAL; 8-bit lookahead table
-inline int derive_table(const uint8_t bits[16], const uint8_t* vals, int nvals, hcir_jpeg_hufftab* t) {
+// packed lookup entry of a symbol (include/hcir.h): consumed bits | zigzag advance << 5 | code length << 10
+inline uint16_t pack_entry(int is_ac, int len, uint8_t sym) {
+  const int ssss = sym & 15, r = sym >> 4;
+  const int adv = !is_ac ? 1 : (ssss ? r + 1 : (r == 15 ? 16 : 0));
+  return (uint16_t)((len + ssss) | (adv << 5) | (len << 10));
+}
+
+// jpeg_make_d_derived_tbl: canonical codes from BITS / HUFFVAL; HCIR_JPEG_LOOK_BITS-bit lookahead table
+inline int derive_table(int is_ac, const uint8_t bits[16], const uint8_t* vals, int nvals, hcir_jpeg_hufftab* t) {
   memset(t, 0, sizeof(*t));
+  t->is_ac = (uint32_t)is_ac;
   uint8_t size[257];
   uint32_t code_of[257];
   int p = 0;
@@ -43,24 +51,38 @@ inline int derive_table(const uint8_t bits[16], const uint8_t* vals, int nvals, 
     code <<= 1;
     ++si;
   }
+  // canonical codes of length l fill [first_l, limit_l) of the left-aligned 16-bit prefix space, lengths ascending
   k = 0;
+  uint32_t lim = 0;
+  t->limit[0] = 0;
   for (int l = 1; l <= 16; ++l) {
     if (bits[l - 1]) {
       t->valoff[l] = k - (int32_t)code_of[k];
       k += bits[l - 1];
-      t->maxcode[l] = (int32_t)code_of[k - 1];
-    } else {
-      t->maxcode[l] = -1;
+      lim = (code_of[k - 1] + 1) << (16 - l);
     }
+    t->limit[l] = lim;
   }
-  t->maxcode[17] = 0xFFFFF;
-  t->maxcode[0] = -1;
+  t->limit[17] = 0x10000;
   k = 0;
-  for (int l = 1; l <= 8; ++l)
+  for (int l = 1; l <= 16; ++l)
     for (int i = 0; i < bits[l - 1]; ++i, ++k) {
-      const uint32_t first = code_of[k] << (8 - l);
-      for (uint32_t j = 0; j < (1u << (8 - l)); ++j) t->look[first + j] = (uint16_t)((l << 8) | vals[k]);
+      if (l > HCIR_JPEG_LOOK_BITS) continue;
+      const uint32_t first = code_of[k] << (HCIR_JPEG_LOOK_BITS - l);
+      for (uint32_t j = 0; j < (1u << (HCIR_JPEG_LOOK_BITS - l)); ++j) t->lut.look[first + j] = pack_entry(is_ac, l, vals[k]);
     }
+  // second level: every longer code lies in [limit[LOOK_BITS], 65536) of the 16-bit prefix space
+  t->lut.base2 = t->limit[HCIR_JPEG_LOOK_BITS];
+  t->lut.use2 = t->lut.base2 >= 0x10000u - HCIR_JPEG_LOOK2 ? 1u : 0u;  // look2 is indexed by the prefix's low bits
+  if (t->lut.use2) {
+    k = 0;
+    for (int l = 1; l <= 16; ++l)
+      for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+        if (l <= HCIR_JPEG_LOOK_BITS) continue;
+        const uint32_t first = (code_of[k] << (16 - l)) - (0x10000u - HCIR_JPEG_LOOK2);
+        for (uint32_t j = 0; j < (1u << (16 - l)); ++j) t->lut.look2[first + j] = pack_entry(is_ac, l, vals[k]);
+      }
+  }
   memcpy(t->vals, vals, (size_t)nvals);
   return HCIR_OK;
 }
@@ -109,7 +131,7 @@ inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
         for (int k = 0; k < 16; ++k) cnt += s[j + 1 + k];
         if (tc > 1 || cnt > 256 || j + 17 + cnt > sl) return HCIR_ERR_INVALID;
         if (th > 1) return HCIR_ERR_UNSUPPORTED;  // baseline allows table ids 0 and 1
-        const int rc = derive_table(s + j + 1, s + j + 17, cnt, &h->huff[tc * 2 + th]);
+        const int rc = derive_table(tc, s + j + 1, s + j + 17, cnt, &h->huff[tc * 2 + th]);
         if (rc != HCIR_OK) return rc;
         have_ht[tc * 2 + th] = true;
         j += 17 + cnt;
@@ -204,39 +226,26 @@ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // upper bound of the staged size: every scan byte kept, + 2 pad words, + the segment table
 inline size_t stage_bound(const hcir_jpeg_header& h, const Scan& s) {
-  return align16(((s.nbytes + 3) / 4 + 2) * 4) + align16(((size_t)h.nsegments + 1) * 4);
+  return align16(((s.nbytes + 3) / 4 + 4) * 4) + align16(((size_t)h.nsegments + 1) * 4);
 }
 
 // The staging copy.  dst must hold stage_bound() bytes.  Returns HCIR_OK and fills stream_bits / stream_words.
 inline int stage(hcir_jpeg_header* h, const Scan& s, uint8_t* dst, size_t* used) {
-  const size_t words_cap = (s.nbytes + 3) / 4 + 2;
-  (void)words_cap;
-  uint32_t* w = reinterpret_cast<uint32_t*>(dst);
   std::vector<uint32_t> seg;
   seg.reserve((size_t)h->nsegments + 1);
   const uint8_t* p = s.data;
   const uint8_t* end = s.data + s.nbytes;
-  size_t nout = 0;  // bytes emitted
-  uint32_t acc = 0;
+  size_t nout = 0;  // bytes emitted (in stream order; the words are byte-swapped in one pass at the end)
   seg.push_back(0);
-  auto emit = [&](const uint8_t* q, size_t cnt) {
-    for (size_t k = 0; k < cnt; ++k) {
-      acc = (acc << 8) | q[k];
-      if ((++nout & 3) == 0) w[nout / 4 - 1] = acc;
-    }
-  };
   while (p < end) {
     const uint8_t* q = (const uint8_t*)memchr(p, 0xFF, (size_t)(end - p));
-    if (!q) {
-      emit(p, (size_t)(end - p));
-      break;
-    }
-    emit(p, (size_t)(q - p));
-    if (q + 1 >= end) break;  // a lone FF at the very end belongs to the next marker
+    const size_t run = (size_t)((q ? q : end) - p);
+    memcpy(dst + nout, p, run);
+    nout += run;
+    if (!q || q + 1 >= end) break;  // a lone FF at the very end belongs to the next marker
     const uint8_t nb = q[1];
     if (nb == 0x00) {
-      const uint8_t ff = 0xFF;
-      emit(&ff, 1);
+      dst[nout++] = 0xFF;
       p = q + 2;
     } else if (nb >= 0xD0 && nb <= 0xD7) {
       if ((int64_t)seg.size() >= h->nsegments) return HCIR_ERR_INVALID;  // more RSTn than the frame has intervals
@@ -250,10 +259,12 @@ inline int stage(hcir_jpeg_header* h, const Scan& s, uint8_t* dst, size_t* used)
   h->stream_bits = (uint32_t)(nout * 8);
   // a stream with fewer RSTn than intervals (truncated file): the missing segments are empty
   while ((int64_t)seg.size() <= h->nsegments) seg.push_back(h->stream_bits);
-  // pad with 1-bits: the last partial word plus two whole words (the reader looks 64 bits ahead)
-  const uint8_t ff = 0xFF;
-  while (nout & 3) emit(&ff, 1);
-  for (int k = 0; k < 8; ++k) emit(&ff, 1);
+  // pad with 1-bits: the last partial word plus four whole words (the reader keeps four words in registers)
+  const size_t padded = (nout + 3) / 4 * 4 + 16;
+  memset(dst + nout, 0xFF, padded - nout);
+  nout = padded;
+  uint32_t* w = reinterpret_cast<uint32_t*>(dst);
+  for (size_t i = 0; i < nout / 4; ++i) w[i] = __builtin_bswap32(w[i]);  // bit 31 = first stream bit
   h->stream_words = (uint32_t)(nout / 4);
   // segment table right behind the words (16-byte aligned): the device finds it from stream_words
   memcpy(dst + align16(nout), seg.data(), seg.size() * 4);

@@ -25,9 +25,14 @@ from . import _lib
 from ._lib import HcirError, check
 
 
+class _Lut(ctypes.Structure):
+    _fields_ = [("look", ctypes.c_uint16 * 2048), ("look2", ctypes.c_uint16 * 256), ("base2", ctypes.c_uint32),
+                ("use2", ctypes.c_uint32)]
+
+
 class _HuffTab(ctypes.Structure):
-    _fields_ = [("look", ctypes.c_uint16 * 256), ("maxcode", ctypes.c_int32 * 18), ("valoff", ctypes.c_int32 * 17),
-                ("vals", ctypes.c_uint8 * 256)]
+    _fields_ = [("lut", _Lut), ("limit", ctypes.c_uint32 * 18), ("valoff", ctypes.c_int32 * 17),
+                ("vals", ctypes.c_uint8 * 256), ("is_ac", ctypes.c_uint32)]
 
 
 class JpegHeader(ctypes.Structure):

@@ -427,11 +427,23 @@ int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream
  * predecessor's chain), prefix-sums the DC differences, and two small kernels for IDCT and
  * upsampling + colour conversion of the MCUs the window touches.
  * ------------------------------------------------------------------ */
+#define HCIR_JPEG_LOOK_BITS 11
+#define HCIR_JPEG_LOOK2 256
+/* One decoded symbol, packed: bits 0-4 = bits consumed (code + magnitude bits, 1..31); bits 5-9 = zigzag advance
+ * (run + 1 for a coefficient, 16 for ZRL, 1 for a DC symbol; 0 = end of block); bits 10-14 = code length.  0 = no
+ * code of at most the indexed length starts with these bits. */
+typedef struct hcir_jpeg_lut { /* the part of a table the device keeps in LDS */
+  uint16_t look[1 << HCIR_JPEG_LOOK_BITS]; /* indexed by the next LOOK_BITS stream bits                           */
+  uint16_t look2[HCIR_JPEG_LOOK2]; /* longer codes, indexed by the low bits of the 16-bit prefix: canonical codes */
+  uint32_t base2;                  /* put the long ones at the top of the prefix space, from base2 on             */
+  uint32_t use2;                   /* base2 >= 65536 - HCIR_JPEG_LOOK2; else long codes take the range search     */
+} hcir_jpeg_lut;
 typedef struct hcir_jpeg_hufftab {
-  uint16_t look[256];  /* (code length << 8) | symbol for codes of <= 8 bits, else 0 */
-  int32_t maxcode[18]; /* largest code of length l, -1 if none; [17] = sentinel        */
-  int32_t valoff[17];  /* symbol index = code + valoff[l]                              */
+  hcir_jpeg_lut lut;
+  uint32_t limit[18]; /* limit[l]: first 16-bit left-aligned prefix that is NOT a code of length <= l       */
+  int32_t valoff[17]; /* symbol index = (prefix >> (16 - l)) + valoff[l]                                    */
   uint8_t vals[256];
+  uint32_t is_ac;
 } hcir_jpeg_hufftab;
 
 typedef struct hcir_jpeg_header {
@@ -442,7 +454,7 @@ typedef struct hcir_jpeg_header {
   int32_t restart_interval;     /* MCUs per restart segment, 0 = none                   */
   int32_t nsegments;            /* entropy-coded segments (restart intervals), >= 1     */
   uint32_t stream_bits;         /* bits of the staged stream (segments concatenated)    */
-  uint32_t stream_words;        /* 32-bit words staged, incl. 2 words of 1-bit padding  */
+  uint32_t stream_words;        /* 32-bit words staged, incl. 3 words of 1-bit padding  */
   uint64_t stage_offset;        /* byte offset of the stream inside the staging blob    */
   uint8_t blk_comp[12];         /* component of block i of an MCU                       */
   uint8_t dc_tab[4], ac_tab[4]; /* per component: index into huff[] (DC 0-1, AC 2-3)    */

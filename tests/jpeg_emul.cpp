@@ -36,24 +36,34 @@ int emul_decode_window(const uint8_t* file, size_t n, int32_t win_h, int32_t win
   rc = jpeg_host::stage(&h, sc, blob.data(), &used);
   if (rc != HCIR_OK) return rc;
 
+  // the interleave kernel: linear word g -> ilv[(g % wps) * nx + g / wps], 1-bits behind the staged words
+  const bool force_generic = nthreads < 0;  // run the plain statement of the decode loop instead of the fast one
+  const uint32_t T = (uint32_t)(nthreads < 0 ? -nthreads : nthreads);
+  JSubseq sq;
+  jpeg_subseq(h.stream_bits, h.stream_words, T, sq);
+  std::vector<uint32_t> ilv((size_t)sq.nx * sq.wps, 0xFFFFFFFFu);
   JStream J;
-  J.words = reinterpret_cast<const uint32_t*>(blob.data());
+  J.wps = sq.wps;
+  J.nx = sq.nx;
+  for (uint32_t g = 0; g < h.stream_words; ++g) ilv[jpeg_word_addr(J, g)] = reinterpret_cast<const uint32_t*>(blob.data())[g];
+  J.words = ilv.data();
   J.seg_start = reinterpret_cast<const uint32_t*>(blob.data() + jpeg_host::align16((size_t)h.stream_words * 4));
   J.nseg = (uint32_t)h.nsegments;
   J.stream_bits = h.stream_bits;
   J.bpm = (uint32_t)h.blocks_per_mcu;
   jpeg_stream_tables(h, J);
+  hcir_jpeg_lut luts[4];
+  for (int i = 0; i < 4; ++i) luts[i] = h.huff[i].lut;  // what the kernel copies into LDS
+  J.luts = luts;
+  J.tabs = h.huff;
+  const bool fast = J.fast2 && !force_generic;
   JWin w;
   jpeg_window(h, win_h, win_w, w);
   memset(out, 0, (size_t)win_h * win_w * 3);
   if (w.last_mcu < 0) return HCIR_OK;
 
   // ---- Huffman kernel, phase 0: speculative decode of every subsequence from (c, z) = (0, 0) ----
-  const uint32_t T = (uint32_t)nthreads;
-  uint32_t S = (h.stream_bits + T - 1) / T;
-  S = (S + 31) & ~31u;
-  if (S < 128) S = 128;
-  const uint32_t nact = (h.stream_bits + S - 1) / S;
+  const uint32_t S = sq.bits, nact = sq.nact;
   std::vector<JState> ctx(nact);
   std::vector<uint64_t> sinfo(nact);
   std::vector<uint32_t> cnt(nact);
@@ -62,7 +72,7 @@ int emul_decode_window(const uint8_t* file, size_t n, int32_t win_h, int32_t win
   auto limit = [&](uint32_t m) { uint64_t l = (uint64_t)(m + 1) * S; return (uint32_t)(l < h.stream_bits ? l : h.stream_bits); };
   for (uint32_t t = 0; t < nact; ++t) {
     jpeg_state_at(J, t * S, 0, 0, ctx[t]);
-    cnt[t] = jpeg_decode_span(J, ctx[t], limit(t), null);
+    cnt[t] = fast ? jpeg_decode_span<true>(J, ctx[t], limit(t), null) : jpeg_decode_span<false>(J, ctx[t], limit(t), null);
     sinfo[t] = jpeg_state_key(ctx[t]);
   }
   // ---- sync loop: in iteration k thread t decodes subsequence t + k from its own chain ----
@@ -76,7 +86,7 @@ int emul_decode_window(const uint8_t* file, size_t n, int32_t win_h, int32_t win
       if (done[t]) continue;
       const uint32_t m = t + k;
       if (m >= nact) { done[t] = 1; continue; }
-      const uint32_t nb = jpeg_decode_span(J, ctx[t], limit(m), null);
+      const uint32_t nb = fast ? jpeg_decode_span<true>(J, ctx[t], limit(m), null) : jpeg_decode_span<false>(J, ctx[t], limit(m), null);
       const uint64_t key = jpeg_state_key(ctx[t]);
       if (sinfo[m] == key) done[t] = 1; else sinfo[m] = key;
       cnt[m] = nb;
@@ -97,9 +107,9 @@ int emul_decode_window(const uint8_t* file, size_t n, int32_t win_h, int32_t win
     JState s;
     if (t == 0) jpeg_state_at(J, 0, 0, 0, s);
     else jpeg_state_at(J, (uint32_t)(sinfo[t - 1] >> 16), (uint32_t)(sinfo[t - 1] >> 8) & 255, (uint32_t)sinfo[t - 1] & 255, s);
-    JWriteSink sink{&h, &w, dcdiff.data(), coef.data(), 0, last_block, -1};
+    JWriteSink sink{&h, &w, dcdiff.data(), coef.data(), 0, last_block, -1, 0, 0, 0};
     sink.begin(first[t]);
-    jpeg_decode_span(J, s, limit(t), sink);
+    if (fast) jpeg_decode_span<true>(J, s, limit(t), sink); else jpeg_decode_span<false>(J, s, limit(t), sink);
   }
   // ---- DC prediction (sequential form; the kernel does a segmented scan) ----
   {

@@ -158,7 +158,7 @@ def test_emulated_device_path_matches_golden(streams, emul):
             rc, _, _ = emul(data, 224, 224)
             assert rc in (-1, -2), name
             continue
-        for threads in (1024, 96):
+        for threads in (1024, 96, -512):  # negative: the generic decode loop (tables outside the fast lookup form)
             rc, out, st = emul(data, 224, 224, threads)
             assert rc == 0, name
             np.testing.assert_array_equal(out, win, err_msg=f"{name} T={threads}")
@@ -176,17 +176,18 @@ def test_emulated_device_path_matches_live_pillow(emul):
                     if grey and ss:
                         continue
                     im = _synth(rng, h, w)
-                    kw = dict(quality=int(rng.choice([30, 75, 95, 100])))
+                    kw = dict(quality=int(rng.choice([30, 75, 95, 100])), optimize=bool(rng.integers(0, 2)))
                     if grey:
                         im = im.convert("L")
                     else:
                         kw["subsampling"] = ss
                     if ri:
                         kw["restart_marker_blocks"] = ri
+                        kw.pop("optimize", None)  # Pillow cannot combine optimised tables with restart markers
                     data = _encode(im, **kw)
                     full = _pil(data)
                     for (wh, ww) in [(224, 224), (h, w), (32, 48)]:
-                        for threads in (7, 1024):
+                        for threads in (7, 1024, -64):
                             rc, out, _ = emul(data, wh, ww, threads)
                             assert rc == 0
                             np.testing.assert_array_equal(out, _window(full, wh, ww),

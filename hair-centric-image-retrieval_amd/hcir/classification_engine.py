@@ -65,6 +65,8 @@ class Classifier:
     def _embed(self, loader, feats, labels):
         for batch in loader:
             images, lab = batch[0], batch[1]
+            if hasattr(images, "decode"):  # hcir.dataloader.EncodedBatch: compressed files, decoded on the device
+                images = images.decode(self.device)
             images = images.to(self.device)
             if images.dtype == torch.uint8:  # raw RGB8 windows [B,H,W,3]: ToTensor + Normalize on the device
                 from .transform import knn_transform_u8

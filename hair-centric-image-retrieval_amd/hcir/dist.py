@@ -86,11 +86,13 @@ class ShardedGallery:
         out = _all_gather_into(q_local, self.world, self.group)      # [P, Q/P, D], rank-major == row order
         return out.view(-1, q_local.shape[1])
 
-    def search_begin(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None):
-        """Enqueue the local scan of this rank's shard; returns a handle for search_finish."""
+    def search_begin(self, q_all: torch.Tensor, k: int, q_inv_norm: Optional[torch.Tensor] = None,
+                     q16: Optional[torch.Tensor] = None):
+        """Enqueue the local scan of this rank's shard; returns a handle for search_finish.  `q16`: the fp16 copy of
+        q_all when the caller already has it (the engine's normalise kernel writes both)."""
         k_local = min(k, self.shard.shape[0])
         if self.resident is not None and q_inv_norm is None and self.g_inv_norm is None:
-            return (self.resident.search_begin(q_all, k_local), k, k_local)
+            return (self.resident.search_begin(q_all, k_local, q16=q16), k, k_local)
         val, idx = self.ops.sim_topk(q_all, self.shard, k_local, q_inv_norm=q_inv_norm,
                                      g_inv_norm=self.g_inv_norm, idx_base=self.idx_base)
         return ((val, idx), k, k_local)

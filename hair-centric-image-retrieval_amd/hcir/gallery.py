@@ -72,7 +72,7 @@ class ResidentGallery:
             + self._gamma * (qn * self._g32max + qf.norm(dim=1) * self._g16max)
         return (e * 1.01 + 1e-7).contiguous()
 
-    def search_begin(self, q32: torch.Tensor, k: int) -> "PendingSearch":
+    def search_begin(self, q32: torch.Tensor, k: int, q16: Optional[torch.Tensor] = None) -> "PendingSearch":
         """Launch filter + refine (asynchronous, no host sync) and return a handle; `finish()` checks
         the certification flags (one host sync) and re-runs uncertified queries through the exact scan.
         Splitting the two lets a caller enqueue its NEXT batch's work before it blocks on the flags,
@@ -82,7 +82,8 @@ class ResidentGallery:
             return PendingSearch(self, q32, k, val, idx, None)
         ops._dev(q32, "q")
         nq, d = q32.shape
-        q16 = q32.to(self.mirror.dtype)
+        if q16 is None or q16.dtype != self.mirror.dtype or q16.shape != q32.shape:
+            q16 = q32.to(self.mirror.dtype)  # callers that already hold the rounded copy (forward_cls(want_f16)) pass it
         cval, cidx = ops.sim_topk(q16, self.mirror, FILTER_KC, idx_base=self.idx_base)
         val = torch.empty((nq, k), dtype=torch.float32, device=q32.device)
         idx = torch.empty((nq, k), dtype=torch.int64, device=q32.device)
@@ -107,10 +108,12 @@ class PendingSearch:
     def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
         g = self.gallery
         if self.cert is not None:
-            bad = (self.cert == 0).nonzero().flatten()  # the one host sync of a batch
+            # the one host sync of a batch: a single reduction; the index list (four more launches) only when needed
+            all_ok = bool(self.cert.min().item())
             g.stats["calls"] += 1
             g.stats["queries"] += self.q32.shape[0]
-            if bad.numel():
+            bad = None if all_ok else (self.cert == 0).nonzero().flatten()
+            if bad is not None and bad.numel():
                 g.stats["fallback_queries"] += int(bad.numel())
                 bv, bi = g.search_exact(self.q32[bad].contiguous(), self.k)
                 self.val[bad] = bv

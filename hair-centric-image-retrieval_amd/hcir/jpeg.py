@@ -127,7 +127,8 @@ _ws = {}
 
 
 def decode_windows(staged: StagedBatch, size: Union[int, Tuple[int, int]] = 224, files: Optional[Sequence[Bytes]] = None,
-                   host_fallback_for_rejected: bool = False, check_status: bool = False) -> torch.Tensor:
+                   host_fallback_for_rejected: bool = False, check_status: bool = False,
+                   _skip_rejected_check: bool = False) -> torch.Tensor:
     """[B, win_h, win_w, 3] uint8 on the blob's device: CenterCrop(size) of every decoded image (zero where the
     window leaves the image, as torchvision pads).  Asynchronous on the current stream unless `check_status`."""
     if not staged.blob.is_cuda:
@@ -150,7 +151,7 @@ def decode_windows(staged: StagedBatch, size: Union[int, Tuple[int, int]] = 224,
     check(L.hcir_jpeg_decode_window_u8(staged.blob.data_ptr(), hdrs, staged.b, win_h, win_w, out.data_ptr(),
                                        None if st is None else st.data_ptr(), ws.data_ptr(), ws.numel(), stream),
           "hcir_jpeg_decode_window_u8")
-    rej = staged.rejected
+    rej = [] if _skip_rejected_check else staged.rejected  # a caller that fills those windows itself
     if rej:
         if not host_fallback_for_rejected or files is None:
             raise HcirError(f"files {rej} are outside the device decoder's baseline-JPEG subset "

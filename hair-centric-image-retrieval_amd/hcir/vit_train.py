@@ -6,11 +6,11 @@ HP/src/pretrain_engine.py:682-745).
     patch_embed -> depth x [ LN1 -> qkv GEMM -> attention (+ log-sum-exp) -> proj GEMM + residual ->
                              LN2 -> fc1 GEMM -> GELU -> fc2 GEMM + residual ] -> final LN of the class token
 keeping, per block, what the backward needs (fp16: block input, qkv, attention output, the residual after the
-attention and the fc1 pre-activation; fp32: the attention's row log-sum-exp: 3.0 MB per image and block at
-T = 197).  Both LayerNorm outputs and the GELU output are RECOMPUTED in the backward (three HBM-bound launches per
-block) instead of stored: 1.8 MB per image and block less, which is what lets config C3's batch of 1024 - three
-differentiable forwards per step - fit in HBM (112 GB of saved activations).  `VitTrainer.backward(saved, d_cls)`
-walks the blocks in reverse:
+attention, the fc1 pre-activation, and — by default, `keep_recomputable=True` — both LayerNorm outputs and the GELU
+output, which are the A operands of the weight-gradient GEMMs; fp32: the attention's row log-sum-exp): 15.4 KB per
+token and block, ~165 GB for config C3's three 1024-image forwards of the 288 GB.  `keep_recomputable=False`
+recomputes the LayerNorm / GELU outputs in the backward instead (three HBM-bound launches per block, 11.8 KB per
+token and block).  `VitTrainer.backward(saved, d_cls)` walks the blocks in reverse:
     dgrad    dX = dY . W          hcir_gemm_f16 against a transposed fp16 copy of the weight
     wgrad    dW = dY^T . X        hcir_gemm_f16_tn (operands as stored, transposed LDS reads, split-M, deterministic)
     bias     db = colsum(dY)      hcir_colsum_f16
@@ -300,8 +300,19 @@ class _VitClsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_cls):
-        grads = ctx.trainer.backward(ctx.saved, d_cls)
+        # The backward's GEMM operands are fp16.  An incoming gradient far from 1 (no GradScaler: d_cls ~ 1e-5 at
+        # batch 1024; or a loss scale of 2^24) would push dS = P (dP - D) and the dgrad operands into fp16's subnormal
+        # / overflow range, so the gradient is renormalised here by a POWER OF TWO (exact in fp32 and fp16) to
+        # max|d_cls| in [0.5, 1), and the fp32 results are scaled back.  Device-side only (no host sync); a
+        # non-finite or all-zero d_cls passes through unscaled, so an overflowed GradScaler step still shows infs.
+        amax = d_cls.detach().abs().max().float()
+        ok = torch.isfinite(amax) & (amax > 0)
+        k = torch.where(ok, -torch.floor(torch.log2(torch.where(ok, amax, torch.ones_like(amax)))) - 1.0,
+                        torch.zeros_like(amax)).clamp_(-100.0, 100.0)
+        up, down = torch.exp2(k), torch.exp2(-k)
+        grads = ctx.trainer.backward(ctx.saved, d_cls * up)
         ctx.saved = None
+        torch._foreach_mul_(grads, down)
         return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.mask))
 
 

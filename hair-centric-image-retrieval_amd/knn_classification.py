@@ -104,10 +104,18 @@ def main(args):
     else:
         from hcir.transform import center_window_u8 as knn_transform
 
-    train_dataset = CustomDataset(args.train_annotation, args.img_dir, knn_transform)
-    test_dataset = CustomDataset(args.test_annotation, args.img_dir, knn_transform)
-    train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
-    test_loader = DataLoader(test_dataset, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
+    if os.environ.get("HCIR_DEVICE_DECODE", "1") == "1" and os.environ.get("HCIR_HOST_TRANSFORM", "0") != "1":
+        # default: the workers read + stage the files, JPEG decode / CenterCrop / ToTensor / Normalize run on the device
+        from hcir.dataloader import EncodedDataset, collate_encoded
+        train_dataset = EncodedDataset(args.train_annotation, args.img_dir)
+        test_dataset = EncodedDataset(args.test_annotation, args.img_dir)
+        kw = dict(collate_fn=collate_encoded)
+    else:
+        train_dataset = CustomDataset(args.train_annotation, args.img_dir, knn_transform)
+        test_dataset = CustomDataset(args.test_annotation, args.img_dir, knn_transform)
+        kw = {}
+    train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers, **kw)
+    test_loader = DataLoader(test_dataset, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers, **kw)
     model = build_model(args)
     trainer = Classifier(model, train_loader, test_loader, args)
     if args.eval_type == "knn":

@@ -83,6 +83,31 @@ def test_vit_backward_vs_oracle_autograd():
     assert _rel(named["encoder.layers.encoder_layer_5.mlp.0.weight"].grad, 2 * g0) <= 1e-6   # and deterministic
 
 
+@pytest.mark.parametrize("scale", [1e-5, 3e4])
+def test_vit_backward_is_scale_invariant(scale):
+    """an incoming gradient of the size a batch-1024 mean loss produces WITHOUT a GradScaler (1e-5), or
+    under a large loss scale, must give the same gradients as an O(1) one, times the scale: the backward renormalises
+    d_cls by a power of two before its fp16 operands are formed (fp16 alone flushes dS = P (dP - D) to zero)."""
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(7)
+    model = SHAM2("vit_b_16").cuda().train()
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    wgt = torch.randn(2, 768, device="cuda")
+    names = ["encoder.layers.encoder_layer_0.self_attention.in_proj_weight", "encoder.layers.encoder_layer_0.ln_1.weight",
+             "encoder.layers.encoder_layer_6.mlp.0.weight", "conv_proj.weight", "encoder.layers.encoder_layer_11.mlp.3.bias"]
+    named = dict(model.backbone.named_parameters())
+
+    def grads(s):
+        model.zero_grad(set_to_none=True)
+        (model.backbone.forward_cls(x) * (wgt * s)).sum().backward()
+        return {n: named[n].grad.detach().clone() for n in names}
+
+    g1, gs = grads(1.0), grads(scale)
+    for n in names:
+        assert torch.isfinite(gs[n]).all(), n
+        assert _rel(gs[n] / scale, g1[n]) <= 5e-3, (n, _rel(gs[n] / scale, g1[n]))
+
+
 def test_vit_backward_gradient_direction_decreases_loss():
     """Independent of any oracle: a small step against the HIP gradient lowers the loss by ~ lr |g|^2."""
     from hcir.main_backbone import SHAM2

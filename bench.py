@@ -682,7 +682,8 @@ def main():
         decode_inc = decode_rates()
         step(xin=x)
         drain()
-        configs = other_configs(dev)
+        with contextlib.redirect_stdout(sys.stderr):  # model constructors print; stdout stays ONE JSON line
+            configs = other_configs(dev)
 
     if rank == 0:
         # HBM-side traffic: PMC counters cannot be read from inside this process; the summaries of separate

@@ -91,6 +91,11 @@ SIGNATURES = {
     "hcir_confusion_matrix": (c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "hcir_retrieval_metrics": (c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                        c_vp]),
+    "hcir_positive_transform": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "hcir_bn1d_fwd": (c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp,
+                              c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "hcir_bn1d_bwd": (c_int, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                              c_i64, c_vp, c_vp, c_vp]),
     "hcir_jpeg_stage_bytes": (c_sz, [c_vp, c_sz]),
     "hcir_jpeg_stage": (c_int, [c_vp, c_sz, c_vp, c_vp, c_sz, c_sz, c_vp]),
     "hcir_jpeg_stage_batch": (c_int, [c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_i32]),

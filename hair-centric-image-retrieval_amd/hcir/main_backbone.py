@@ -51,15 +51,23 @@ class SimCLRProjectionHead(nn.Module):
             nn.Linear(input_dim, hidden_dim, bias=False), nn.BatchNorm1d(hidden_dim), nn.ReLU(),
             nn.Linear(hidden_dim, output_dim, bias=False), nn.BatchNorm1d(output_dim))
 
+    def _hip_trainable(self) -> bool:
+        lin0, _, _, lin1, _ = self.layers
+        return all(f % 256 == 0 for f in (lin0.in_features, lin0.out_features, lin1.out_features))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.layers(x)
+        if self.training and x.is_cuda and self._hip_trainable():
+            # train mode on the HIP path: batch-statistics BatchNorm kernels + hcir GEMMs, forward and backward
+            # (hcir.head_train); the ViT head (768, 768, 512) and the ResNet-50 head (2048, 2048, 1024) qualify
+            from .head_train import head_train_forward
+            return head_train_forward(self, x)
+        return self.layers(x)   # CPU tensors / the ResNet-18 head (128 outputs): torch modules, as the trunk is
 
     # eval-mode forward on the HIP device: two GEMMs with the BatchNorm folded into the
     # epilogue (scale = w / sqrt(var + eps), shift = b - mean * scale)
     def forward_hip(self, x16: torch.Tensor) -> torch.Tensor:
         if self.training:
-            raise NotImplementedError("projection head in train mode (batch statistics + backward) "
-                                      "is not on the HIP path yet")
+            return self.forward(x16.float())
         L = _lib.lib()
         lin0, bn0, _, lin1, bn1 = self.layers
         dev = x16.device
@@ -205,6 +213,19 @@ class SHAM2(nn.Module):
             return self._vit_project(self.backbone, self.projection_head, x)
         x = self.backbone(x).flatten(start_dim=1)
         return self.projection_head(x)
+
+    def forward_views(self, views):
+        """[self(v) for v in views] — what the step computes at HP/src/pretrain_engine.py:683-690 (negatives,
+        positives, anchors) — with ONE differentiable backbone pass over the concatenated views: the ViT has no batch
+        coupling (LayerNorm only), so every row comes out as in a pass of its own, while the GEMM / TN-GEMM tile
+        counts fill whole rounds of the 256 CUs and the launch count drops to a third.  The projection head, whose
+        BatchNorm1d takes BATCH statistics, still runs once per view, in order (running statistics as in the
+        reference)."""
+        if "vit" in self.model and self.projection_head.training:
+            sizes = [int(v.shape[0]) for v in views]
+            cls = self.backbone.forward_cls(torch.cat(list(views)))
+            return [self.projection_head(c) for c in cls.split(sizes)]
+        return [self.forward(v) for v in views]
 
     @torch.no_grad()
     def forward_momentum(self, x):

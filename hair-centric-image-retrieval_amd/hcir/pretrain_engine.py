@@ -15,12 +15,15 @@
     total = contrastive + 0.5 triplet + 0.2 mse                (:735-742, ablation switches kept)
     scaler.scale(total).backward(); unscale_; clip_grad_norm_(1.0); scaler.step; scaler.update    (:745-749)
 
-What stays torch: the optimizer (torch.optim.Adam from utils.get_optimizer, :108), GradScaler, clip_grad_norm_ and
-the lightly projection head (nn.Linear / BatchNorm1d modules, as in the reference).  The data loader, the epoch
-bookkeeping, logging and checkpointing of the reference's Trainer are outside the hot path.
-`positive_transform` (RandomRotation + GaussianBlur augmentation, HP/utils/transform.py:21-24) is an augmentation
-policy, not arithmetic of the step: the caller passes its own callable (default: identity = the reference's
-"No_pos_transform" ablation).
+    positive_transform(pos)  (RandomRotation + GaussianBlur)   hcir.transform        hcir_positive_transform
+    projection head in train mode (Linear/BN/ReLU/Linear/BN)   hcir.head_train       hcir_gemm_f16 / _tn, hcir_bn1d_*
+
+The step's DEFAULT path is the reference's default path: `positive_transform` on (ablation "No_pos_transform" turns
+it off, :684-685), hard negatives mined once in the epoch that ends the warm-up with k from the previous epoch's margin
+violations and cached per batch (:633-654), "fixed_hard" and "randomly" as in the reference.  What stays torch: the
+optimizer (torch.optim.Adam from utils.get_optimizer, :108), GradScaler and clip_grad_norm_ — no vendor GEMM is left
+in the step.  The data loader, the epoch bookkeeping, logging and checkpointing of the reference's Trainer are outside
+the hot path.
 """
 from __future__ import annotations
 
@@ -33,7 +36,7 @@ from .losses import NTXentLoss
 from .momentum import update_momentum
 from .neg_sampling import NegSamplerRandomly, NegSamplerStatic
 from .train_ops import TripletMarginLoss, mse_loss
-from .transform import PositiveMaskingTransform
+from .transform import PositiveMaskingTransform, PositiveTransform
 
 
 class SHAMTrainStep:
@@ -54,14 +57,44 @@ class SHAMTrainStep:
             self.triplet_loss_stage1 = TripletMarginLoss(margin=0.7, p=2, eps=1e-7)             # :96
             self.triplet_loss_stage2 = TripletMarginLoss(margin=0.5, p=2, eps=1e-7)             # :97
         self.positive_masking_transform = PositiveMaskingTransform(mask_ratio_range=mask_ratio_range)   # :99
-        self.positive_transform = positive_transform
+        # HP/utils/transform.py:21-24 applied at :686 unless ablation == "No_pos_transform" (:684-685); a caller may
+        # pass its own callable
+        self.positive_transform = positive_transform if positive_transform is not None else PositiveTransform()
         self.negative_batch_idx = []
+        self.total_k = 0
+
+    def hard_negative_k(self, prev_margin_violations: float, batch_size: int) -> int:
+        """:636-642 — x = max(2, round((1 - v) * 10)) with v = the previous epoch's margin violations per sample
+        (Python's round: ties to even, as in the reference)."""
+        v = prev_margin_violations / batch_size
+        return max(2, round((1 - v) * 10))
+
+    def _negatives(self, x_pos_1, epoch, batch_id, prev_margin_violations, negative_idx):
+        """:627-680.  Stage 1 (epoch + 1 < warm_up_epochs) and the "randomly" ablation draw random negatives.  In the
+        epoch that ends the warm-up (epoch + 1 == warm_up_epochs) every batch is mined ONCE with the momentum model
+        (NegSamplerStatic, k from the schedule above, fixed at batch 0) and its indices are cached; every later epoch
+        re-uses the cache by batch id (the reference's loader order is fixed).  "fixed_hard" takes the cached / mined
+        indices in every epoch — before the mining epoch the cache is empty and the reference raises IndexError."""
+        model = self.model
+        if negative_idx is not None:                       # caller-supplied indices (tests, external caches)
+            return x_pos_1[negative_idx]
+        stage1 = self.warm_up_epochs > epoch + 1
+        if self.ablation == "randomly" or (stage1 and self.ablation != "fixed_hard"):
+            return NegSamplerRandomly(x_pos_1)                                                  # :631,660
+        if (epoch + 1) == self.warm_up_epochs:
+            if batch_id == 0:
+                self.negative_batch_idx = []                                                    # :635
+                self.total_k = self.hard_negative_k(prev_margin_violations, x_pos_1.shape[0])   # :637-642
+            self.negative_batch_idx.append(NegSamplerStatic(model, x_pos_1, k=self.total_k))    # :644,670
+        if batch_id >= len(self.negative_batch_idx):
+            raise IndexError(f"no cached hard-negative indices for batch {batch_id}: they are mined in epoch "
+                             f"{self.warm_up_epochs - 1} (epoch + 1 == warm_up_epochs), HP/src/pretrain_engine.py:633-654")
+        return x_pos_1[self.negative_batch_idx[batch_id]]                                       # :654,680
 
     def __call__(self, batch: Dict[str, torch.Tensor], epoch: int = 0, negative_idx: Optional[torch.Tensor] = None,
-                 generator=None) -> Dict[str, float]:
-        """One optimisation step on {'anchor', 'pos1'} image batches [B,3,224,224] (HIP device).  Stage 1
-        (epoch + 1 < warm_up_epochs) draws random negatives; otherwise `negative_idx` (NegSamplerStatic's output for
-        this batch, :643,652) selects them, or they are mined here with k = 2."""
+                 generator=None, batch_id: int = 0, prev_margin_violations: float = 0.0) -> Dict[str, float]:
+        """One optimisation step on {'anchor', 'pos1'} image batches [B,3,224,224] (HIP device): the body of the
+        reference's batch loop; `batch_id` and `prev_margin_violations` are the loop's own variables (:618, :602)."""
         model, opt, scaler = self.model, self.optimizer, self.scaler
         model.train()
         opt.zero_grad()
@@ -69,17 +102,14 @@ class SHAMTrainStep:
         update_momentum(model.projection_head, model.projection_head_momentum, m=self.momentum)  # :622
         x_anchor, x_pos_1 = batch["anchor"], batch["pos1"]
         stage1 = self.warm_up_epochs > epoch + 1
-        if stage1 or self.ablation == "randomly":
-            negative_samples = NegSamplerRandomly(x_pos_1)                                      # :631,660
-        else:
-            if negative_idx is None:
-                negative_idx = NegSamplerStatic(model, x_pos_1, k=2)                            # :646 (k from :638-642)
-            negative_samples = x_pos_1[negative_idx]                                            # :654
+        negative_samples = self._negatives(x_pos_1, epoch, batch_id, prev_margin_violations, negative_idx)
 
-        neg_batch = model(negative_samples)                                                     # :683
-        pos_samples = x_pos_1 if self.positive_transform is None else self.positive_transform(x_pos_1)   # :684-687
-        pos_batch = model(pos_samples)                                                          # :689
-        anchor_batch = model(x_anchor)                                                          # :690
+        pos_samples = x_pos_1 if self.ablation == "No_pos_transform" else self.positive_transform(x_pos_1)   # :684-687
+        # :683,689,690 — model(neg), model(pos), model(anchor): one 3B-row backbone pass, the head once per view
+        if hasattr(model, "forward_views"):
+            neg_batch, pos_batch, anchor_batch = model.forward_views([negative_samples, pos_samples, x_anchor])
+        else:
+            neg_batch, pos_batch, anchor_batch = model(negative_samples), model(pos_samples), model(x_anchor)
         if self.ablation == "No masked positive":
             masked_pos_samples = pos_samples
         else:

@@ -112,3 +112,57 @@ class PositiveMaskingTransform:
         u = torch.empty(b, device=images.device).uniform_(lo, hi, generator=generator)
         keys = torch.rand((b, npatch), device=images.device, generator=generator)
         return self.apply(images, u, keys)
+
+
+class PositiveTransform:
+    """`positive_transform` of HP/utils/transform.py:21-24 — T.Compose([T.RandomRotation((-15, 15)),
+    T.GaussianBlur(kernel_size=3, sigma=(0.1, 0.5))]) — as the step applies it to the DEVICE batch
+    (HP/src/pretrain_engine.py:686), on the HIP path (hcir_positive_transform: one kernel for both).
+
+    torchvision draws ONE angle and ONE sigma per call for a batch tensor, from torch's CPU generator
+    (`torch.empty(1).uniform_(lo, hi)`, rotation first, then blur): `__call__` draws them the same way, so a seeded
+    run takes the same augmentation parameters as the reference; `apply(images, angle, sigma)` takes them explicitly
+    (what the parity test drives)."""
+
+    def __init__(self, degrees=(-15.0, 15.0), kernel_size: int = 3, sigma=(0.1, 0.5)):
+        if kernel_size != 3:
+            raise ValueError("hcir_positive_transform implements the reference's kernel_size=3")
+        self.degrees = (float(degrees[0]), float(degrees[1]))
+        self.sigma = (float(sigma[0]), float(sigma[1]))
+
+    @staticmethod
+    def params_to_host_arrays(angle: float, sigma: float):
+        """(theta4, taps2) as torchvision derives them: F.rotate -> _get_inverse_affine_matrix([0, 0], -angle, ...),
+        _get_gaussian_kernel1d(3, sigma) in float32."""
+        import ctypes
+        import math
+        rot = math.radians(-angle)
+        theta = torch.tensor([math.cos(rot), math.sin(rot), -math.sin(rot), math.cos(rot)], dtype=torch.float32)
+        x = torch.linspace(-1.0, 1.0, steps=3, dtype=torch.float32)
+        pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+        k = pdf / pdf.sum()
+        return (ctypes.c_float * 4)(*theta.tolist()), (ctypes.c_float * 2)(float(k[0]), float(k[1]))
+
+    def apply(self, images: torch.Tensor, angle: float, sigma: float) -> torch.Tensor:
+        from . import _lib
+        from ._lib import HcirError, check
+        if not isinstance(images, torch.Tensor) or images.dim() != 4:
+            raise HcirError("positive_transform takes a [B, C, H, W] tensor")
+        if not images.is_cuda:
+            raise HcirError(f"images are on {images.device}; PositiveTransform runs on a HIP device only")
+        x = images.float().contiguous()
+        b, c, h, w = x.shape
+        out = torch.empty_like(x)
+        theta4, taps2 = self.params_to_host_arrays(float(angle), float(sigma))
+        check(_lib.lib().hcir_positive_transform(x.data_ptr(), b, c, h, w, theta4, taps2, out.data_ptr(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream),
+              "hcir_positive_transform")
+        return out
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        angle = float(torch.empty(1).uniform_(self.degrees[0], self.degrees[1]).item())   # RandomRotation.get_params
+        sigma = float(torch.empty(1).uniform_(self.sigma[0], self.sigma[1]).item())        # GaussianBlur.get_params
+        return self.apply(images, angle, sigma)
+
+
+positive_transform = PositiveTransform()

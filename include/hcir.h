@@ -402,6 +402,31 @@ int hcir_mse_bwd(const float* x, const float* y, int64_t n, const float* grad_ou
 /* fp32 -> fp16 / bf16 conversion of a contiguous buffer (gallery upload). */
 int hcir_convert_f32(const float* x, int64_t n, int dtype, void* y, void* stream);
 
+/* positive_transform of the pretrain step (HP/utils/transform.py:21-24, applied to the device batch at
+ * HP/src/pretrain_engine.py:686): T.RandomRotation((-15, 15)) (nearest neighbour, zero fill) followed by
+ * T.GaussianBlur(kernel_size=3) (reflect padding), in one kernel.  torchvision draws ONE angle and ONE sigma per call
+ * for a batch tensor; the caller draws them and passes, as HOST arrays, theta4 = {a, b, c, d} of torchvision's inverse
+ * affine matrix [[a, b, 0], [c, d, 0]] (= {cos r, sin r, -sin r, cos r}, r = radians(-angle)... computed as
+ * torchvision's _get_inverse_affine_matrix does) and taps2 = {k(+-1), k(0)} of the normalised 3-tap Gaussian.
+ * images / out fp32 [B][C][H][W], must not alias. */
+int hcir_positive_transform(const float* images, int64_t b, int32_t c, int32_t h, int32_t w, const float* theta4,
+                            const float* taps2, float* out, void* stream);
+
+/* BatchNorm1d in TRAINING mode over x fp32 [rows][f] (lightly SimCLRProjectionHead, HP/src/main_backbone.py:589):
+ * batch mean / biased variance, y = (x - mean) rstd gamma + beta (+ ReLU), running statistics updated with `momentum`
+ * and the unbiased variance as torch does (running_* may be NULL).  Outputs y_f32 and / or y_f16 (one may be NULL);
+ * save_mean / save_rstd [f] are kept for the backward. */
+int hcir_bn1d_fwd(const float* x, int64_t ldx, int64_t rows, int32_t f, const float* gamma, const float* beta,
+                  float eps, float momentum, int relu, float* running_mean, float* running_var, float* save_mean,
+                  float* save_rstd, float* y_f32, int64_t ldy32, void* y_f16, int64_t ldy16, void* stream);
+/* Its backward: dx (fp16 [rows][f], the operand of the dgrad / wgrad GEMMs in front), dgamma, dbeta [f].
+ * relu_out_f16 (optional): the forward's fp16 ReLU output; the incoming gradient is zero where it is <= 0.
+ * dy_scale (optional DEVICE scalar): dy is multiplied by it first (the caller's power-of-two renormalisation). */
+int hcir_bn1d_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t rows, int32_t f,
+                  const float* gamma, const float* save_mean, const float* save_rstd, const void* relu_out_f16,
+                  int64_t ldr, const float* dy_scale, void* dx_f16, int64_t lddx, float* dgamma, float* dbeta,
+                  void* stream);
+
 /* ------------------------------------------------------------------ *
  * Baseline-JPEG decode on the device.  Replaces
  *   read_file + torchvision.io.decode_image(img_bytes, mode=RGB)      HP/utils/dataloader.py:28-31

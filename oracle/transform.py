@@ -68,3 +68,36 @@ def positive_masking(images: np.ndarray, u: np.ndarray, keys: np.ndarray, patch_
             out[b, :, ph * patch_size:(ph + 1) * patch_size, pw * patch_size:(pw + 1) * patch_size] = 0.0
         counts[b] = num_mask
     return out, counts
+
+
+def positive_transform(images, angle: float, sigma: float):
+    """`positive_transform` (HP/utils/transform.py:21-24) on a batch tensor, restated with torch CPU ops from
+    torchvision's PUBLIC source (torchvision is not installed here: PARITY UNPINNED for this function):
+      RandomRotation -> F.rotate(img, angle, NEAREST, expand=False, center=None, fill=0):
+        theta = _get_inverse_affine_matrix([0, 0], -angle, [0, 0], 1, [0, 0]) = [[cos r, sin r, 0], [-sin r, cos r, 0]],
+        r = radians(-angle); grid = _gen_affine_grid (pixel centres, theta^T / (w/2, h/2));
+        grid_sample(nearest, zeros, align_corners=False)
+      GaussianBlur(3, sigma) -> reflect-pad by 1, depthwise conv2d with outer(k1d, k1d), k1d = normalised
+        exp(-0.5 (x / sigma)^2) on x = linspace(-1, 1, 3)
+    images: float32 torch tensor [B, C, H, W] (CPU)."""
+    import math
+    import torch
+    import torch.nn.functional as F
+    b, c, h, w = images.shape
+    rot = math.radians(-angle)
+    theta = torch.tensor([[math.cos(rot), math.sin(rot), 0.0], [-math.sin(rot), math.cos(rot), 0.0]],
+                         dtype=torch.float32).reshape(1, 2, 3)
+    d = 0.5
+    base = torch.empty(1, h, w, 3, dtype=torch.float32)
+    base[..., 0].copy_(torch.linspace(-w * 0.5 + d, w * 0.5 + d - 1, steps=w))
+    base[..., 1].copy_(torch.linspace(-h * 0.5 + d, h * 0.5 + d - 1, steps=h).unsqueeze(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)
+    grid = base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2).expand(b, h, w, 2)
+    rotated = F.grid_sample(images, grid, mode="nearest", padding_mode="zeros", align_corners=False)
+    x = torch.linspace(-1.0, 1.0, steps=3, dtype=torch.float32)
+    pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+    k1 = pdf / pdf.sum()
+    k2 = torch.mm(k1[:, None], k1[None, :]).expand(c, 1, 3, 3)
+    padded = F.pad(rotated, [1, 1, 1, 1], mode="reflect")
+    return F.conv2d(padded, k2, groups=c)

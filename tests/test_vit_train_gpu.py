@@ -108,6 +108,30 @@ def test_vit_backward_is_scale_invariant(scale):
         assert _rel(gs[n] / scale, g1[n]) <= 5e-3, (n, _rel(gs[n] / scale, g1[n]))
 
 
+def test_forward_views_equals_separate_calls():
+    """SHAM2.forward_views (one 3B-row backbone pass, the head per view) against three model(x) calls: same outputs
+    (the backbone has no batch coupling; BatchNorm1d sees one view at a time either way, running statistics
+    included), gradients equal up to the weight-gradient GEMM's summation order."""
+    import copy
+    from hcir.main_backbone import SHAM2
+    torch.manual_seed(11)
+    m1 = SHAM2("vit_b_16").cuda().train()
+    m2 = copy.deepcopy(m1)
+    views = [torch.randn(n, 3, 224, 224, device="cuda") for n in (5, 5, 5)]
+    w = [torch.randn(5, 512, device="cuda") for _ in range(3)]
+    o1 = [m1(v) for v in views]
+    o2 = m2.forward_views(views)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    sum((a * ww).sum() for a, ww in zip(o1, w)).backward()
+    sum((a * ww).sum() for a, ww in zip(o2, w)).backward()
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p1.grad is not None:
+            assert _rel(p2.grad, p1.grad) <= 1e-4, n1
+    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), n1
+
+
 def test_vit_backward_gradient_direction_decreases_loss():
     """Independent of any oracle: a small step against the HIP gradient lowers the loss by ~ lr |g|^2."""
     from hcir.main_backbone import SHAM2
@@ -153,9 +177,15 @@ def test_sham_train_step_matches_oracle_forward_and_trains():
     with torch.no_grad():
         for pm, p in zip(head_m.parameters(), head.parameters()):
             pm.copy_(pm * 0.99 + p * (1.0 - 0.99))
+    # the step's DEFAULT path applies positive_transform (HP/src/pretrain_engine.py:686): torchvision draws one angle
+    # and one sigma per call from torch's CPU generator; the same seed gives the HIP step the same two numbers
+    from oracle import transform as otf
+    torch.manual_seed(77)
+    angle = float(torch.empty(1).uniform_(-15.0, 15.0).item())
+    sigma = float(torch.empty(1).uniform_(0.1, 0.5).item())
     with torch.no_grad():
         z_neg = head(ovit.vitwrapper_forward(sd, batch["pos1"][neg_idx], "backbone.")[0])
-        z_pos = head(ovit.vitwrapper_forward(sd, batch["pos1"], "backbone.")[0])
+        z_pos = head(ovit.vitwrapper_forward(sd, otf.positive_transform(batch["pos1"], angle, sigma), "backbone.")[0])
         z_anc = head(ovit.vitwrapper_forward(sd, batch["anchor"], "backbone.")[0])
     n_neg, n_pos, n_anc = (F.normalize(z, dim=1) for z in (z_neg, z_pos, z_anc))
     ref_trip = float(torch.nn.TripletMarginLoss(margin=0.5, p=2, eps=1e-7)(n_anc, n_pos, n_neg))
@@ -168,6 +198,7 @@ def test_sham_train_step_matches_oracle_forward_and_trains():
                          ablation="No masked positive")
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     dev_batch = {k: v.cuda() for k, v in batch.items()}
+    torch.manual_seed(77)           # the two uniform_ draws of positive_transform are the first CPU draws of the step
     out = step(dev_batch, epoch=0, negative_idx=neg_idx.cuda())
     assert abs(out["triplet"] - ref_trip) <= 5e-3 * max(1.0, abs(ref_trip)), (out["triplet"], ref_trip)
     assert abs(out["contrastive"] - ref_con) <= 5e-3 * max(1.0, abs(ref_con)), (out["contrastive"], ref_con)

@@ -689,8 +689,10 @@ def main():
         # HBM-side traffic: PMC counters cannot be read from inside this process; the summaries of separate
         # `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this same command are committed under profiles/
         # together with the hash of the kernel sources they were taken on, and reported ONLY for the same sources
-        from hcir._lib import source_hash
-        src = source_hash()
+        # ... of the BINARY that is loaded (hcir_build_id: the source hash it was compiled from + its -D flags), so a
+        # stale .so or an HCIR_LIB_PATH variant is never credited with another build's byte counts
+        from hcir._lib import build_id
+        src = build_id()
 
         def recorded(name, key):
             try:

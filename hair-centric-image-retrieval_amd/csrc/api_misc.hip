@@ -1,5 +1,12 @@
-// api_misc.hip — version / status strings of the C ABI.
+// api_misc.hip — version / status strings / build identity of the C ABI.
 #include "common.h"
+
+#ifndef HCIR_BUILD_ID
+#define HCIR_BUILD_ID "unknown"
+#endif
+#ifndef HCIR_BUILD_FLAGS
+#define HCIR_BUILD_FLAGS ""
+#endif
 
 extern "C" {
 int hcir_version(void) {
@@ -15,4 +22,8 @@ const char* hcir_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+// "<sha256/16 of the sources this binary was compiled from>[ <-D flags>]": tools/build_variant.sh builds (A/B and
+// ablation libraries) carry their flags, so a PMC summary can never be attributed to the wrong binary
+const char* hcir_build_id(void) { return HCIR_BUILD_ID HCIR_BUILD_FLAGS; }
 }

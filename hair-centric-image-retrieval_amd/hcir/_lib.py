@@ -33,6 +33,7 @@ c_i32, c_i64, c_f32, c_vp, c_sz, c_int = (
 SIGNATURES = {
     "hcir_version": (c_int, []),
     "hcir_status_string": (ctypes.c_char_p, [c_int]),
+    "hcir_build_id": (ctypes.c_char_p, []),
     "hcir_row_invnorm": (c_int, [c_vp, c_i64, c_i32, c_i64, c_int, c_f32, c_vp, c_vp]),
     "hcir_l2_normalize": (c_int, [c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "hcir_sim_topk_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32, c_int]),
@@ -109,19 +110,18 @@ class HcirError(RuntimeError):
 
 
 def source_hash() -> str:
-    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip, *.h,
-    include/hcir.h), in sorted name order.  Recorded next to every PMC traffic summary under profiles/ so that
-    bench.py can tell a summary of THIS build from a stale one."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC_DIR, "*.hip")) + glob.glob(os.path.join(CSRC_DIR, "*.h")))
-    files.append(os.path.join(os.path.dirname(_PKG_DIR), "include", "hcir.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """sha256 (first 16 hex digits) over the kernel sources ON DISK (csrc/*.hip, *.h, include/hcir.h), in sorted name
+    order.  The same digest is embedded in the binary at build time (`build_id()`)."""
+    from ._srchash import source_hash as _h
+    return _h(CSRC_DIR, os.path.join(os.path.dirname(_PKG_DIR), "include", "hcir.h"))
+
+
+def build_id() -> str:
+    """Identity of the LOADED binary: "<source hash it was compiled from>[ -D flags]" (hcir_build_id).  Recorded next
+    to every PMC summary under profiles/; bench.py reports a summary only when it carries the loaded binary's id, so a
+    stale .so or a tools/_libhcir_<tag>.so variant loaded through HCIR_LIB_PATH can never be credited with numbers
+    taken on another binary."""
+    return lib().hcir_build_id().decode()
 
 
 def build(verbose: bool = False) -> str:

@@ -67,18 +67,31 @@ def convert(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 class _WorkspaceCache:
     """Scratch buffers for the C ABI (which allocates nothing itself), one per (device, stream): two streams
-    never share a buffer, so concurrent calls cannot race on it.  A buffer grows on demand and is dropped when a
-    much smaller one is asked for (a one-off k = 642 sweep does not pin its gigabytes for the process lifetime)."""
+    never share a buffer, so concurrent calls cannot race on it.  A buffer grows on demand and is dropped only after
+    SHRINK_AFTER consecutive requests that would fit an eighth of it (a one-off k = 642 sweep does not pin its
+    gigabytes for the process lifetime, while a training backward that alternates 66 MB weight-gradient workspaces
+    with KB-sized reductions keeps ONE buffer instead of re-allocating it several hundred times per step)."""
+
+    SHRINK_AFTER = 64
 
     def __init__(self):
         self._buf = {}
+        self._small = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
         key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self._buf.get(key)
-        if b is None or b.numel() < nbytes or b.numel() > max(8 * nbytes, 64 << 20):
-            b = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-            self._buf[key] = b
+        if b is not None and b.numel() >= nbytes:
+            if b.numel() > max(8 * nbytes, 64 << 20):
+                self._small[key] = self._small.get(key, 0) + 1
+                if self._small[key] < self.SHRINK_AFTER:
+                    return b
+            else:
+                self._small[key] = 0
+                return b
+        b = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        self._buf[key] = b
+        self._small[key] = 0
         return b
 
 

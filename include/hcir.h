@@ -44,6 +44,9 @@ typedef enum {
 
 int hcir_version(void);
 const char* hcir_status_string(int status);
+/* "<16 hex digits: sha256 of the kernel sources this binary was compiled from>[ -D build flags]".  bench.py reports a
+ * recorded PMC summary only when it was taken on a binary with this id. */
+const char* hcir_build_id(void);
 
 /* ------------------------------------------------------------------ *
  * Row norms.  out[i] = 1 / max(||x_i||_2, eps)   (fp32)

@@ -30,8 +30,8 @@ def main():
            "algorithmic_bytes": alg, "ratio": (rd + wr) / alg,
            "per_kernel_read_bytes": {k: int(2 * 1024 * sum(v) / calls) for k, v in f.items()}}
     try:
-        from hcir._lib import source_hash
-        res["src_hash"] = source_hash()
+        from hcir._lib import build_id
+        res["src_hash"] = build_id()   # identity of the binary the counters were taken on
     except Exception as e:  # noqa: BLE001
         res["src_hash"] = None
     json.dump(res, open(out, "w"), indent=1)

@@ -61,8 +61,8 @@ def main():
                    "fc1+GELU, <7> proj / fc2 with row statistics, <6> plain fp16-residual epilogue.",
            "kernels": kernels, "gemm_f16_big_kernel_avg_bytes_per_launch": int(avg)}
     try:  # which build these counters belong to (bench.py reports them only for the same sources)
-        from hcir._lib import source_hash
-        res["src_hash"] = source_hash()
+        from hcir._lib import build_id
+        res["src_hash"] = build_id()   # identity of the binary the counters were taken on
     except Exception as e:  # noqa: BLE001
         res["src_hash"] = None
         print("source hash unavailable:", e)

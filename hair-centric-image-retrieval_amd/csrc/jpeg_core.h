@@ -117,6 +117,8 @@ struct JBitWin {
   }
   JHD uint32_t peek(const JStream& J, uint32_t p) {
     const uint32_t i = p >> 5;
+    // (a refill under a branch, so that the new word would first be touched at the NEXT refill, was tried: hipcc
+    // rotates the window registers at the loop's back edge and waits for the load in every iteration all the same)
     const bool adv = i != wi;
     w0 = adv ? w1 : w0;
     w1 = adv ? w2 : w1;

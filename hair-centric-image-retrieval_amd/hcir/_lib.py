@@ -83,6 +83,8 @@ SIGNATURES = {
                                  c_vp]),
     "hcir_attn_fwd_lse": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "hcir_attn_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
+    "hcir_attn_cls_fwd_lse": (c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "hcir_attn_cls_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp]),
     "hcir_triplet_margin_fwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "hcir_triplet_margin_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp]),

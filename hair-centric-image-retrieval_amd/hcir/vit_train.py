@@ -41,14 +41,17 @@ def _pad64(m: int) -> int:
 
 class _Saved:
     """Activations of one training forward (device buffers; rows padded to a multiple of 64 with zeros)."""
-    __slots__ = ("b", "t", "m", "x_in", "qkv", "att", "lse", "x_mid", "u", "ln1", "ln2", "h", "x_out", "patches")
+    __slots__ = ("b", "t", "m", "x_in", "qkv", "att", "lse", "x_mid", "u", "ln1", "ln2", "h", "x_out", "patches", "last")
 
 
 class VitTrainer:
     """fp16 operand copies of a ViT's weights (as stored and transposed) + the training forward / backward."""
 
-    def __init__(self, spec: VitSpec, device: torch.device, keep_recomputable: bool = True):
+    def __init__(self, spec: VitSpec, device: torch.device, keep_recomputable: bool = True,
+                 cls_only_last: bool = True):
         self.keep_recomputable = bool(keep_recomputable)
+        # forward() returns the class token only, so the last block's other rows are dead work (see forward)
+        self.cls_only_last = bool(cls_only_last)
         if device.type != "cuda":
             raise HcirError(f"VitTrainer needs a HIP device, got {device} (no CPU fallback)")
         if spec.dim % spec.heads or spec.dim // spec.heads != 64:
@@ -156,15 +159,56 @@ class VitTrainer:
         # LayerNorm and one GELU launch per layer in the backward (keep_recomputable=False restores the recompute).
         keep = self.keep_recomputable
         ln, h = (None, None) if keep else (z16(d), z16(self.mlp))
-        for w in self.lw:
-            qkv, att = z16(3 * d), z16(d)
-            lse = torch.empty((b, self.heads, t), dtype=torch.float32, device=dev)
+        sv.last = None
+        for li, w in enumerate(self.lw):
+            qkv = z16(3 * d)
             if keep:
                 ln = z16(d)
             self._ln(cur, m, d, d, w["ln1_w"], w["ln1_b"], ln, st)
             if keep:
                 sv.ln1.append(ln)
             self._gemm(ln, d, w["qkv_w"], w["qkv_b"], m, 3 * d, _lib.EPI_BIAS_F16, qkv, st, "hcir_gemm_f16(qkv)")
+            if self.cls_only_last and li == len(self.lw) - 1:
+                # Only the class token feeds the loss (HP/src/main_backbone.py:625-627): in the LAST block the other
+                # queries, and proj / LN2 / MLP of their rows, are dead in the forward and in the backward.  K and V
+                # of every token are still needed (the qkv GEMM above); everything behind runs on the b class-token
+                # rows, compact buffers [pad64(b), .] (as the inference engine has done since round 1).
+                bp = _pad64(b)
+
+                def c16(cols):
+                    buf = torch.empty((bp, cols), dtype=torch.float16, device=dev)
+                    if bp > b:
+                        buf[b:].zero_()
+                    return buf
+                att_c, xin_c, x_mid_c, ln2_c, u_c, h_c, x_out_c = (c16(d), c16(d), c16(d), c16(d), c16(self.mlp),
+                                                                   c16(self.mlp), c16(d))
+                lse_c = torch.empty((b, self.heads), dtype=torch.float32, device=dev)
+                check(L.hcir_attn_cls_fwd_lse(qkv.data_ptr(), b, t, self.heads, d // self.heads, scale, att_c.data_ptr(),
+                                              lse_c.data_ptr(), st), "hcir_attn_cls_fwd_lse")
+                xin_c[:b] = cur[:m].view(b, t, d)[:, 0]
+                self._gemm(att_c, d, w["proj_w"], w["proj_b"], b, d, _lib.EPI_BIAS_RESID_F16, x_mid_c, st,
+                           "hcir_gemm_f16(proj, cls rows)", resid=xin_c)
+                self._ln(x_mid_c, b, d, d, w["ln2_w"], w["ln2_b"], ln2_c, st)
+                if L.hcir_gemm_fused_supported(b, self.mlp, d):
+                    check(L.hcir_gemm_f16_gelu_dual(ln2_c.data_ptr(), d, w["fc1_w"].data_ptr(), d, _p(w["fc1_b"]), b,
+                                                    self.mlp, d, u_c.data_ptr(), h_c.data_ptr(), self.mlp, st),
+                          "hcir_gemm_f16_gelu_dual(cls rows)")
+                else:
+                    self._gemm(ln2_c, d, w["fc1_w"], w["fc1_b"], b, self.mlp, _lib.EPI_BIAS_F16, u_c, st,
+                               "hcir_gemm_f16(fc1, cls rows)")
+                    check(L.hcir_gelu_fwd_f16(u_c.data_ptr(), b * self.mlp, h_c.data_ptr(), st), "hcir_gelu_fwd_f16")
+                self._gemm(h_c, self.mlp, w["fc2_w"], w["fc2_b"], b, d, _lib.EPI_BIAS_RESID_F16, x_out_c, st,
+                           "hcir_gemm_f16(fc2, cls rows)", resid=x_mid_c)
+                sv.last = dict(att=att_c, lse=lse_c, x_mid=x_mid_c, ln2=ln2_c, u=u_c, h=h_c, x_out=x_out_c)
+                sv.x_in.append(cur)
+                sv.qkv.append(qkv)
+                sv.x_out = None
+                cls = torch.empty((b, d), dtype=torch.float32, device=dev)
+                check(L.hcir_cls_head(x_out_c.data_ptr(), _lib.F16, b, 1, d, self.fln_w.data_ptr(), self.fln_b.data_ptr(),
+                                      self.eps, 0, cls.data_ptr(), None, st), "hcir_cls_head")
+                return cls, sv
+            att = z16(d)
+            lse = torch.empty((b, self.heads, t), dtype=torch.float32, device=dev)
             T.attn_fwd_lse(qkv, b, t, self.heads, scale, att, lse)
             x_mid = z16(d)       # out of place: `cur` is this block's saved input
             self._gemm(att, d, w["proj_w"], w["proj_b"], m, d, _lib.EPI_BIAS_RESID_F16, x_mid, st, "hcir_gemm_f16(proj)",
@@ -206,8 +250,15 @@ class VitTrainer:
         dy16 = torch.zeros((mp, d), dtype=torch.float16, device=dev)
         g_flw, g_flb = f32z(d), f32z(d)
         dcls16 = d_cls.detach().to(device=dev, dtype=torch.float16).contiguous()
-        T.layernorm_bwd(sv.x_out, dcls16, self.fln_w, self.eps, None, dres, g_flw, g_flb, accumulate=False, rows=b,
-                        ldx=t * d, ldr=t * d)
+        lastc = sv.last          # class-token-only last block: its residual gradient lives in a compact [pad64(b), d] buffer
+        if lastc is None:
+            T.layernorm_bwd(sv.x_out, dcls16, self.fln_w, self.eps, None, dres, g_flw, g_flb, accumulate=False, rows=b,
+                            ldx=t * d, ldr=t * d)
+        else:
+            bp = _pad64(b)
+            dres_c = f32z(bp, d)
+            T.layernorm_bwd(lastc["x_out"], dcls16, self.fln_w, self.eps, None, dres_c, g_flw, g_flb, accumulate=False,
+                            rows=b, ldx=d, ldr=d)
         big16 = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)     # d_h / d_u
         # gelu(u) / LayerNorm output: recomputed per block only when the forward did not keep them
         hbuf = None if sv.h else torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)
@@ -228,6 +279,39 @@ class VitTrainer:
                 ("ln1_w", (d,)), ("ln1_b", (d,)), ("qkv_w", (3 * d, d)), ("qkv_b", (3 * d,)), ("proj_w", (d, d)),
                 ("proj_b", (d,)), ("ln2_w", (d,)), ("ln2_b", (d,)), ("fc1_w", (self.mlp, d)), ("fc1_b", (self.mlp,)),
                 ("fc2_w", (d, self.mlp)), ("fc2_b", (d,)))}
+            if lastc is not None and li == len(self.lw) - 1:
+                # ---- last block on the b class-token rows (compact buffers); K / V gradients for every token
+                z16c = lambda cols: torch.zeros((bp, cols), dtype=torch.float16, device=dev)
+                dy16_c, big16_c, dln_c, datt_c = z16c(d), z16c(self.mlp), z16c(d), z16c(d)
+                check(L.hcir_add_f32_f16(dres_c.data_ptr(), None, b * d, dy16_c.data_ptr(), st), "hcir_add_f32_f16")
+                T.colsum(dy16_c, g["fc2_b"], accumulate=False, rows=b)
+                self._gemm(dy16_c, d, w["fc2_wt"], None, b, self.mlp, _lib.EPI_BIAS_F16, big16_c, st, "dgrad(fc2, cls)")
+                T.gemm_tn(dy16_c, lastc["h"], g["fc2_w"], accumulate=False)
+                T.gelu_bwd_colsum(lastc["u"], big16_c, big16_c, g["fc1_b"], rows=b)
+                self._gemm(big16_c, self.mlp, w["fc1_wt"], None, b, d, _lib.EPI_BIAS_F16, dln_c, st, "dgrad(fc1, cls)")
+                T.gemm_tn(big16_c, lastc["ln2"], g["fc1_w"], accumulate=False)
+                T.layernorm_bwd(lastc["x_mid"], dln_c, w["ln2_w"], self.eps, dres_c, dres_c, g["ln2_w"], g["ln2_b"],
+                                accumulate=False, rows=b, dres16=dy16_c, dres_colsum=g["proj_b"])
+                self._gemm(dy16_c, d, w["proj_wt"], None, b, d, _lib.EPI_BIAS_F16, datt_c, st, "dgrad(proj, cls)")
+                T.gemm_tn(dy16_c, lastc["att"], g["proj_w"], accumulate=False)
+                check(L.hcir_attn_cls_bwd(sv.qkv[li].data_ptr(), lastc["att"].data_ptr(), datt_c.data_ptr(),
+                                          lastc["lse"].data_ptr(), b, t, self.heads, d // self.heads, scale,
+                                          dqkv.data_ptr(), st), "hcir_attn_cls_bwd")
+                # the block's residual gradient: the class-token rows carry dres_c, every other row nothing (yet)
+                dres[:m].view(b, t, d)[:, 0] = dres_c[:b]
+                self._gemm(dqkv, 3 * d, w["qkv_wt"], None, m, d, _lib.EPI_BIAS_F16, dln, st, "dgrad(qkv)")
+                if sv.ln1:
+                    lncur = sv.ln1[li]
+                else:
+                    lncur = lnbuf
+                    self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
+                T.gemm_tn(dqkv, lncur, g["qkv_w"], accumulate=False)
+                T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
+                fc2_b_next = f32z(d) if li > 0 else None
+                T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
+                                accumulate=False, rows=m, dres16=dy16 if li > 0 else None, dres_colsum=fc2_b_next)
+                layer_grads.append(g)
+                continue
             # ---- MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
             if fc2_b_next is None:
                 check(L.hcir_add_f32_f16(dres.data_ptr(), None, nelem, dy16.data_ptr(), st), "hcir_add_f32_f16")

@@ -388,6 +388,15 @@ int hcir_attn_fwd_lse(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t 
 int hcir_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, int64_t b, int32_t t,
                   int32_t h, int32_t hd, float scale, void* d_qkv, void* stream);
 
+/* The same pair for the CLASS-TOKEN query only (token 0 of every image): the last block of a training pass whose loss
+ * reads cls_token = x[:, 0] alone (HP/src/main_backbone.py:625-627).  out / d_out fp16 [B][H*64] (compact), lse fp32
+ * [B][H]; d_qkv [B][T][3][H][64] receives dK, dV of every token, dQ of token 0 and ZERO for the other tokens' dQ.
+ * hd == 64, T <= 256. */
+int hcir_attn_cls_fwd_lse(const void* qkv, int64_t b, int32_t t, int32_t h, int32_t hd, float scale, void* out,
+                          float* lse, void* stream);
+int hcir_attn_cls_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, int64_t b, int32_t t,
+                      int32_t h, int32_t hd, float scale, void* d_qkv, void* stream);
+
 /* nn.TripletMarginLoss(margin, p=2, eps, reduction='mean') (HP/src/pretrain_engine.py:96-97,717-721), fp32 [B][D]:
  *   d(x, y) = || x - y + eps ||_2,  loss = mean_i max(d(a_i, p_i) - d(a_i, n_i) + margin, 0).
  * row_loss [B] and dist [2][B] are kept for the backward; grad_out is a DEVICE scalar. */

@@ -152,8 +152,10 @@ class SHAMTrainStep:
             total_loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
             opt.step()
-        out.update(total=float(total_loss), contrastive=float(contrastive_loss),
-                   triplet=float(triplet_loss) if triplet_loss is not None else 0.0,
-                   mse=float(mse) if mse is not None else 0.0, pos_dist=float(pos_dist.mean()),
-                   neg_dist=float(neg_dist.mean()), margin_violations=float(violations.sum()))
+        zero = total_loss.new_zeros(())
+        # one device-to-host read for the step's seven scalars
+        vals = torch.stack([v.detach().float() for v in (
+            total_loss, contrastive_loss, triplet_loss if triplet_loss is not None else zero,
+            mse if mse is not None else zero, pos_dist.mean(), neg_dist.mean(), violations.sum())]).tolist()
+        out.update(zip(("total", "contrastive", "triplet", "mse", "pos_dist", "neg_dist", "margin_violations"), vals))
         return out

@@ -48,3 +48,21 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+
+// LDS-DMA (global_load_lds_dwordx4: 16 B per lane to wave-uniform base + lane * 16) issued OUTSIDE the compiler's
+// view.  With the builtin, hipcc's waitcnt pass treats every ds_read_b64_tr_b16 (a builtin without a memory operand
+// it could disambiguate) as possibly aliasing the pending transfer and puts `s_waitcnt vmcnt(0)` in front of it: a
+// stage prefetched under a loop of transposed reads was waited for at the loop's first read (seen in the .s of
+// gemm_tn and attn_bwd).  As inline asm the transfer is invisible to that pass; callers retire it with an explicit
+// `s_waitcnt vmcnt(0)` before the barrier that publishes the stage.  VMEM operations the compiler does not know of
+// only make the vmcnt(N) it computes for its own loads stricter (returns are in order), never wrong.
+// Source = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset; destination = wave-uniform LDS byte address
+// (lds_addr() of the 1 KB the 64 lanes fill).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void lds_dma16(const void* src_base, uint32_t src_off, uint32_t lds_wave_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(src_off), "s"(src_base), "s"(m)
+               : "memory");
+}

@@ -60,11 +60,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_tn_kernel(TnArgs g) {
   const char* abase = reinterpret_cast<const char*>(g.a) + m_begin * g.lda * 2;
   const char* bbase = reinterpret_cast<const char*>(g.b) + m_begin * g.ldb * 2;
   const int64_t astep = 64 * g.lda * 2, bstep = 64 * g.ldb * 2;
+  const uint32_t lds0 = lds_addr(lds);
   auto issue = [&](int step, int i) {  // i < 8 constant after unrolling: 0..3 A pieces, 4..7 B pieces
+#ifdef HCIR_TN_DMA_BUILTIN   // build flag (A/B): the compiler-visible transfer, which the waitcnt pass retires with
+                             // vmcnt(0) in front of the next transposed read, i.e. inside the step that issued it
     const char* sp = i < 4 ? abase + step * astep + aoff[i & 3] : bbase + step * bstep + boff[i & 3];
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)sp,
         (__attribute__((address_space(3))) void*)(lds + (step & 1) * SLOT + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
+#else
+    lds_dma16(i < 4 ? abase + step * astep : bbase + step * bstep, i < 4 ? aoff[i & 3] : boff[i & 3],
+              lds0 + (step & 1) * SLOT + ((tid & ~63) + 512 * i) * 16);
+#endif
   };
 
   f32x4 acc[8][4];

@@ -22,6 +22,8 @@
 // P is recomputed from the forward's per-row log2-sum-exp (hcir_attn_fwd_lse); D from dO and O at kernel start.
 // LDS: Q, dO, K images (3 x 32 KB), dS staging 16 KB, dQ slabs 4 x 8.3 KB, row constants 2 KB: 1 workgroup per CU.
 // The images carry the row-read swizzle only; transposed reads see some bank conflicts.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -306,6 +308,17 @@ __global__ __launch_bounds__(64 * (8 / KT), 1) void attn_bwd_kernel(AttnBwdArgs 
 // LDS images.  The chunk swizzle (bit-reversed (row >> 1) & 7) is conflict-free for the row reads AND for the
 // transposed reads (a half wave reads 4 consecutive rows x 64 B: rows r, r + 2 land in different 64-B windows).
 constexpr int kRows2 = 224;
+#ifdef HCIR_ATTN_BWD_STAMPS   // diagnostic build (tools/diag_attn_bwd.py): wave 0 of workgroup 0 stamps the phase
+                              // boundaries of its fourth item with (s_memtime, s_memrealtime)
+__device__ unsigned long long g_attn_bwd_stamps[16];
+#define AB2_STAMP(i)                                                         \
+  if (blockIdx.x == 0 && tid == 0 && nitem == 3) {                           \
+    g_attn_bwd_stamps[2 * (i)] = __builtin_amdgcn_s_memtime();               \
+    g_attn_bwd_stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();       \
+  }
+#else
+#define AB2_STAMP(i)
+#endif
 constexpr int kImg2 = kRows2 * 128;
 constexpr int kNW2 = kRows2 / 32;
 
@@ -314,6 +327,10 @@ __device__ __forceinline__ int swz2(int row) {
 }
 __device__ __forceinline__ int img2_off(int row, int c16) { return row * 128 + ((c16 ^ swz2(row)) << 4); }
 __device__ __forceinline__ int img2_off_e(int row, int e0) { return img2_off(row, e0 >> 3) + (e0 & 7) * 2; }
+
+#ifndef HCIR_AB2_STAGGER
+#define HCIR_AB2_STAGGER 0   // s_sleep units (64 cycles) the second wave of each SIMD starts a pass late (A/B flag)
+#endif
 
 __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, int items) {
   __shared__ __attribute__((aligned(16))) char lds[5 * kImg2 + 2 * 256 * 4];
@@ -328,76 +345,94 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int grp = lane >> 4, li = lane & 15;
-  const int64_t qkv_stride = (int64_t)3 * a.h * 64, o_stride = (int64_t)a.h * 64;
-  const int nrows = 32 * nw;
-  const int myrow = 32 * wave + r;                          // this lane's key (pass 1) / query (pass 2)
+  const int qkv_stride = 3 * a.h * 64, o_stride = a.h * 64;   // elements between tokens
+  const int myrow = 32 * wave + r;                            // this lane's key (pass 1) / query (pass 2)
   const int myrow_c = myrow < a.t ? myrow : a.t - 1;
   const bool live = myrow < a.t;
-
-  // one image = 4 nw wave instructions of 8 rows; wave w issues instructions w, w + nw, ...  (rows past T: the last
-  // real row - finite data; P is exactly 0 there through lse = +inf (queries) or the key mask).  The per-lane source
-  // byte offsets are the same for every item: row * pitch + swizzled chunk, for the two row pitches in use.
-  uint32_t offq[4], offo[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int row = (wave + u * nw) * 8 + (lane >> 3), pc = lane & 7;
-    const int src = row < a.t ? row : a.t - 1;
-    offq[u] = (uint32_t)(src * (int)qkv_stride * 2 + ((pc ^ swz2(row)) << 4));
-    offo[u] = (uint32_t)(src * (int)o_stride * 2 + ((pc ^ swz2(row)) << 4));
-  }
   const uint32_t lds0 = lds_addr(lds);
-  auto dma_image = [&](const char* img, const _Float16* g, const uint32_t (&off)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) lds_dma16(g, off[u], lds0 + (uint32_t)(img - lds) + (wave + u * nw) * 1024);
+
+  // One image = 4 nw wave instructions of 8 rows; piece u (0..3) of wave w is instruction w + u nw.  Rows past T
+  // fetch the last real row: finite data; P is exactly 0 there through lse = +inf (queries) or the key mask.
+  // Memory instructions are NOT issued in bursts: a burst of 12 transfers + 8 loads + 8 stores per wave stood 7-10 k
+  // cycles at the head of a pass (the issuing wave stalls while the CU's memory pipe is backlogged - the kernel
+  // moves 202 KB per item, ~20 k cycles at the CU's share of HBM); piece u goes out at the top of tile min(u, nw - 1)
+  // of the pass it hides under, the row stores in the tiles behind.
+  auto dma_piece = [&](const char* img, const _Float16* g, int stride, int u) {
+    const int ii = wave + u * nw;
+    const int row = ii * 8 + (lane >> 3), pc = lane & 7;
+    const int src = row < a.t ? row : a.t - 1;
+    lds_dma16(g, (uint32_t)(src * stride * 2 + ((pc ^ swz2(row)) << 4)), lds0 + (uint32_t)(img - lds) + ii * 1024);
   };
+  auto piece_tile = [&](int u) { return u < nw - 1 ? u : nw - 1; };
   auto qkv_base = [&](int item) { return ((int64_t)(item / a.h) * a.t) * qkv_stride + (item % a.h) * 64; };
   auto o_base = [&](int item) { return ((int64_t)(item / a.h) * a.t) * o_stride + (item % a.h) * 64; };
-  const uint32_t myq_off = (uint32_t)(myrow_c * (int)qkv_stride * 2 + 16 * h);   // bytes: this lane's row, dims 8 h ..
+  auto issue_r0 = [&](int item, int u) {
+    const int64_t ob = o_base(item);
+    dma_piece(qs, a.qkv + qkv_base(item), qkv_stride, u);
+    dma_piece(dos, a.dout + ob, o_stride, u);
+    dma_piece(os, a.out + ob, o_stride, u);
+  };
 
   f16x8 kf[4], vf[4];   // K / V rows of this wave's keys: B operands of pass 1
   float lv = 0.f;
-  auto prefetch = [&](int item) {
-    const _Float16* qg = a.qkv + qkv_base(item);
-    const int64_t ob = o_base(item);
-    dma_image(qs, qg, offq);
-    dma_image(dos, a.dout + ob, offo);
-    dma_image(os, a.out + ob, offo);
-    const char* kg = reinterpret_cast<const char*>(qg + (int64_t)a.h * 64);
-    const char* vg = reinterpret_cast<const char*>(qg + (int64_t)2 * a.h * 64);
+  auto load_frags = [&](int item) {
+    const char* kg = reinterpret_cast<const char*>(a.qkv + qkv_base(item) + (int64_t)a.h * 64);
+    const char* vg = kg + (int64_t)a.h * 64 * 2;
+    const uint32_t off = (uint32_t)(myrow_c * qkv_stride * 2 + 16 * h);   // this lane's row, dims 8 h ..
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      kf[s] = *reinterpret_cast<const f16x8*>(kg + (myq_off + 32 * s));
-      vf[s] = *reinterpret_cast<const f16x8*>(vg + (myq_off + 32 * s));
+      kf[s] = *reinterpret_cast<const f16x8*>(kg + (off + 32 * s));
+      vf[s] = *reinterpret_cast<const f16x8*>(vg + (off + 32 * s));
     }
     lv = __builtin_huge_valf();
-    if (tid < a.t) lv = (a.lse + (int64_t)item * a.t)[tid];
+    if ((tid >> 1) < a.t) lv = (a.lse + (int64_t)item * a.t)[tid >> 1];   // row tid / 2: see the D phase
   };
 
-  f32x16 dqa[2];
-  int prev = -1;
-  // dQ = scale dQ^T: lane = query, registers = dims in groups of 4
-  auto store_rows = [&](_Float16* g, const f32x16 (&acc)[2], float mul) {
-    char* gp = reinterpret_cast<char*>(g);
-    const uint32_t off = (uint32_t)(myrow * (int)qkv_stride * 2 + 8 * h);
+  // Rows leave in 16-B pieces: a lane pair (r, r + 32) holds one row of the transposed accumulators in alternating
+  // 8-B pieces (dims 8 g + 4 h ..), so one v_permlane32_swap per dword hands each lane two adjacent pieces (chunk c
+  // of half 0: dims 16 c .. + 7, of half 1: dims 16 c + 8 .. + 15).  As 8-B stores every instruction touched 32
+  // lines twice over.
+  auto pack_rows = [&](const f32x16 (&acc)[2], float mul, u32x4 (&o)[4]) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f16x4 o;
+      for (int j = 0; j < 2; ++j) {
+        f16x4 x, y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(acc[dt][4 * g4 + e] * mul);
-        *reinterpret_cast<f16x4*>(gp + (off + 64 * dt + 16 * g4)) = o;
+        for (int e = 0; e < 4; ++e) {
+          x[e] = (_Float16)(acc[dt][8 * j + e] * mul);
+          y[e] = (_Float16)(acc[dt][8 * j + 4 + e] * mul);
+        }
+        u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(xu[d], yu[d], false, false);
+          xu[d] = sw[0];
+          yu[d] = sw[1];
+        }
+        o[2 * dt + j] = (u32x4){xu[0], xu[1], yu[0], yu[1]};
       }
   };
-  auto store_dq = [&](int item) {
-    if (live) store_rows(a.dqkv + qkv_base(item), dqa, a.scale);
+  const uint32_t row_off = (uint32_t)(myrow * qkv_stride * 2 + 16 * h);
+  auto store_chunk = [&](_Float16* g, int c, const u32x4& v) {
+    if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g) + (row_off + 32 * c)) = v;
   };
 
+  u32x4 dqo[4];   // the previous item's dQ rows, packed: stored behind the next barrier
+  int prev = -1;
   int item = blockIdx.x;
-  if (item < items) prefetch(item);
+  if (item < items) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) issue_r0(item, u);
+    load_frags(item);
+  }
+  [[maybe_unused]] int nitem = 0;
   while (item < items) {
     const int64_t qb = qkv_base(item);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // R0 of this item has landed (issued a pass ago)
+    const _Float16* kgl = a.qkv + qb + (int64_t)a.h * 64;
+    const _Float16* vgl = kgl + (int64_t)a.h * 64;
+    AB2_STAMP(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // R0 of this item has landed (issued under the previous pass 2)
     // the fragments / lse prefetched with it have landed too: take them out of the compiler's pending set, or it
     // re-waits (vmcnt(0)) at their first use, behind the K / V transfer issued below
     asm volatile("" : "+v"(lv));
@@ -407,30 +442,50 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
       asm volatile("" : "+v"(vf[s]));
     }
     __syncthreads();                                   // ... and every wave has left pass 2 of the previous item
-    if (prev >= 0) store_dq(prev);
-    dma_image(ks, a.qkv + qb + (int64_t)a.h * 64, offq);
-    dma_image(vs, a.qkv + qb + (int64_t)2 * a.h * 64, offq);
-    if (tid < nrows) {
+    AB2_STAMP(1)
+    if (prev >= 0) {
+      _Float16* dqg = a.dqkv + qkv_base(prev);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) store_chunk(dqg, c, dqo[c]);
+    }
+    {  // D[q] = <dO[q], O[q]>: two threads per row (blockDim = 2 x rows), four 16-B chunks each
+      const int drow = tid >> 1, dc = (tid & 1) * 4;
       float dsv = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const f16x8 ov = *reinterpret_cast<const f16x8*>(os + img2_off(tid, c));
-        const f16x8 dv = *reinterpret_cast<const f16x8*>(dos + img2_off(tid, c));
+      for (int c = 0; c < 4; ++c) {
+        const f16x8 ov = *reinterpret_cast<const f16x8*>(os + img2_off(drow, dc + c));
+        const f16x8 dv = *reinterpret_cast<const f16x8*>(dos + img2_off(drow, dc + c));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dsv = __builtin_fmaf((float)ov[e], (float)dv[e], dsv);
+        for (int e = 0; e < 8; e += 2) {
+          const f16x2 x = {ov[e], ov[e + 1]}, y = {dv[e], dv[e + 1]};
+          dsv = __builtin_amdgcn_fdot2(x, y, dsv, false);
+        }
       }
-      dsum[tid] = dsv;
-      lrow[tid] = lv;
+      dsv += __shfl_xor(dsv, 1);
+      if ((tid & 1) == 0) {
+        dsum[drow] = dsv;
+        lrow[drow] = lv;
+      }
     }
     __syncthreads();
+    AB2_STAMP(2)
+#if HCIR_AB2_STAGGER > 0
+    if (wave >= 4) __builtin_amdgcn_s_sleep(HCIR_AB2_STAGGER);
+#endif
 
-    // ---- pass 1: this wave's keys against every query tile
+    // ---- pass 1: this wave's keys against every query tile; the K / V images (R1) go out under its first tiles
     f32x16 dkt[2], dvt[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int i = 0; i < 16; ++i) dkt[x][i] = dvt[x][i] = 0.f;
     for (int qt = 0; qt < nw; ++qt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (piece_tile(u) == qt) {
+          dma_piece(ks, kgl, qkv_stride, u);
+          dma_piece(vs, vgl, qkv_stride, u);
+        }
       const int q0 = qt * 32;
       f16x8 qf[4], dof[4];
 #pragma unroll
@@ -450,8 +505,8 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float lq = lrow[q0 + acc_row(i, h)], dq = dsum[q0 + acc_row(i, h)];
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], a.scale_log2e, -lq));
-        p = live ? p : 0.f;
+        // keys past T (this lane's column) need no mask here: they only reach dK^T / dV^T columns that are never stored
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], a.scale_log2e, -lq));
         pf[i >> 3][i & 7] = (_Float16)p;
         dsf[i >> 3][i & 7] = (_Float16)(p * (dp[i] - dq));
       }
@@ -481,6 +536,7 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
         }
       }
     }
+    AB2_STAMP(3)
     // Q / dO rows of this wave's QUERIES (B operands of pass 2) and their row constants, while R0 is still this item's
     f16x8 qb2[4], dob2[4];
 #pragma unroll
@@ -489,22 +545,41 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
       dob2[s] = *reinterpret_cast<const f16x8*>(dos + img2_off(myrow, 2 * s + h));
     }
     const float lq2 = lrow[myrow], dq2 = dsum[myrow];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // R1 has landed (issued before pass 1)
+    // dK = scale dK^T, dV = dV^T: lane = key, registers = dims; packed now, stored under pass 2
+    u32x4 dko[4], dvo[4];
+    pack_rows(dkt, a.scale, dko);
+    pack_rows(dvt, 1.f, dvo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // R1 has landed (issued under the first tiles of pass 1)
     __syncthreads();                                   // ... and every wave is done with R0
-    // dK = scale dK^T, dV = dV^T: lane = key, registers = dims in groups of 4
-    if (live) {
-      store_rows(a.dqkv + qb + (int64_t)a.h * 64, dkt, a.scale);
-      store_rows(a.dqkv + qb + (int64_t)2 * a.h * 64, dvt, 1.f);
-    }
+    AB2_STAMP(4)
+#if HCIR_AB2_STAGGER > 0
+    if (wave >= 4) __builtin_amdgcn_s_sleep(HCIR_AB2_STAGGER);
+#endif
     const int next = item + gridDim.x;
-    if (next < items) prefetch(next);   // R0, kf / vf, lse of the next item: in flight under pass 2
+    const bool has_next = next < items;
+    // the next item's register fragments: here, not inside the loop below - there the compiler guards the rewrite of
+    // these registers with a vmcnt wait that also retires the transfers issued just before it
+    if (has_next) load_frags(next);
 
-    // ---- pass 2: this wave's queries against every key tile
+    // ---- pass 2: this wave's queries against every key tile; the next item's R0, its fragments and this item's
+    //      dK / dV rows go out under it
+    f32x16 dqa[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int i = 0; i < 16; ++i) dqa[x][i] = 0.f;
-    for (int kt = 0; kt < nw; ++kt) {
+    auto key_tile = [&](int kt, auto masked) {
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (piece_tile(u) == kt) issue_r0(next, u);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (piece_tile(c + 3) == kt) {
+          store_chunk(a.dqkv + qb + (int64_t)a.h * 64, c, dko[c]);
+          store_chunk(a.dqkv + qb + (int64_t)2 * a.h * 64, c, dvo[c]);
+        }
       const int k0 = kt * 32;
       f16x8 ka[4], va[4];
 #pragma unroll
@@ -524,7 +599,7 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], a.scale_log2e, -lq2));
-        p = k0 + acc_row(i, h) < a.t ? p : 0.f;
+        if (decltype(masked)::value) p = k0 + acc_row(i, h) < a.t ? p : 0.f;   // keys past T: the last tile only
         dsb[i >> 3][i & 7] = (_Float16)(p * (dpt[i] - dq2));
       }
       // dQ^T += K^T dS^T: A operand by transposed reads of the K image in the accumulator operand's k order
@@ -545,14 +620,29 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
           dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf, dsb[s], dqa[dt], 0, 0, 0);
         }
       }
-    }
+    };
+    for (int kt = 0; kt + 1 < nw; ++kt) key_tile(kt, std::false_type{});
+    key_tile(nw - 1, std::true_type{});
+    pack_rows(dqa, a.scale, dqo);   // dQ = scale dQ^T: lane = query
+    AB2_STAMP(6)
     prev = item;
     item = next;
+    ++nitem;
   }
-  if (prev >= 0) store_dq(prev);
+  if (prev >= 0) {
+    _Float16* dqg = a.dqkv + qkv_base(prev);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) store_chunk(dqg, c, dqo[c]);
+  }
 }
 
 }  // namespace
+
+#ifdef HCIR_ATTN_BWD_STAMPS
+extern "C" int hcir_diag_attn_bwd_stamps(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_attn_bwd_stamps), sizeof(g_attn_bwd_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int hcir_attn_bwd(const void* qkv, const void* out, const void* d_out, const float* lse, int64_t b,
                              int32_t t, int32_t h, int32_t hd, float scale, void* d_qkv, void* stream) {

@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
     const XT* xr = x + row * ldx;
     const _Float16* dr = dy + row * lddy;
     float xv[NJ][4], dv[NJ][4];
+    f32x4 rin[NJ];   // the residual gradient of the row, requested with x and dy (behind the three reductions its
+                     // HBM latency stood exposed once per row)
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (j < nj) {
         const int c = 4 * (lane + 64 * j);
+        rin[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c < d) {
+          if (dres_in) rin[j] = *reinterpret_cast<const f32x4*>(dres_in + row * ldr + c);
           if constexpr (sizeof(XT) == 2) {
             const f16x4 xq = *reinterpret_cast<const f16x4*>(xr + c);
 #pragma unroll
@@ -172,11 +176,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rstd * (dv[j][e] - mg - xv[j][e] * mgx);
-          if (dres_in) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(dres_in + row * ldr + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += r0[e];
-          }
+          for (int e = 0; e < 4; ++e) o[e] += rin[j][e];
           *reinterpret_cast<f32x4*>(dres_out + row * ldr + c) = o;
           if (dres16) {
             f16x4 oh;
@@ -218,26 +219,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const XT* __restrict
   }
 }
 
-// out[c] (+)= sum_p part[p][c]: workgroup = 64 columns x 4 part lanes (lane q sums parts q, q + 4, ... in order, the
-// four sums are then added in lane order: a fixed tree, deterministic); blockIdx.y selects one of `narr` independent
-// (part, out) pairs laid out back to back (LayerNorm: dgamma and dbeta in one launch).  A one-thread-per-column loop
-// over ~800 partial rows took 105 us per call (13 % of a training step's GPU time).
+// out[c] (+)= sum_p part[p][c]: workgroup = 16 columns x 16 part lanes (lane q sums parts q, q + 16, ... in order,
+// the sixteen sums are then added in lane order: a fixed tree, deterministic); blockIdx.y selects one of up to three
+// independent (part, out) pairs laid out back to back (LayerNorm: dgamma, dbeta and the bias gradient of the Linear
+// in front in ONE launch); bit y of acc_mask = accumulate into out y.  History: a one-thread-per-column loop over
+// ~800 partial rows took 105 us per call, 64 columns x 4 part lanes 30 us (2.7 ms of a training step over ~90 calls).
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int parts, int n,
                                                               float* __restrict__ out0, float* __restrict__ out1,
-                                                              int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+                                                              float* __restrict__ out2, int acc_mask) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   const float* src = part + (int64_t)blockIdx.y * parts * n;
-  float* out = blockIdx.y == 0 ? out0 : out1;
+  float* out = blockIdx.y == 0 ? out0 : (blockIdx.y == 1 ? out1 : out2);
   float s = 0.f;
   if (c < n)
-    for (int p = pl; p < parts; p += 4) s += src[(int64_t)p * n + c];
+    for (int p = pl; p < parts; p += 16) s += src[(int64_t)p * n + c];
   red[pl][cl] = s;
   __syncthreads();
   if (pl == 0 && c < n) {
-    const float t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
-    out[c] = accumulate ? out[c] + t : t;
+    float t = red[0][cl];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][cl];
+    out[c] = ((acc_mask >> blockIdx.y) & 1) ? out[c] + t : t;
   }
 }
 
@@ -436,8 +440,8 @@ int hcir_add_f32_f16(const float* a, const float* b, int64_t n, void* y, void* s
 }
 
 int32_t hcir_layernorm_bwd_blocks(int64_t rows) {
-  int64_t b = hcir_cdiv(rows, 4 * 16);  // >= 16 rows per wave
-  return (int32_t)(b < 1 ? 1 : (b > 512 ? 512 : b));
+  int64_t b = hcir_cdiv(rows, 4 * 16);  // >= 16 rows per wave; 1024 workgroups = 4 waves per SIMD in flight
+  return (int32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
 int hcir_layernorm_bwd(const void* x, int x_dtype, int64_t rows, int32_t d, int64_t ldx, const void* dy_f16,
@@ -488,14 +492,9 @@ int hcir_layernorm_bwd_fused(const void* x, int x_dtype, int64_t rows, int32_t d
 #undef LNB_NJ
 #undef LNB
   HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 64), 2), dim3(256), 0, st, gpart, blocks, d,
-                     dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 16), (unsigned)narr), dim3(256), 0, st, gpart,
+                     blocks, d, dgamma, dbeta, dres_colsum, accumulate ? 3 : 0);
   HCIR_LAUNCH_CHECK();
-  if (dres_colsum) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(d, 64), 1), dim3(256), 0, st, rpart, blocks, d,
-                       dres_colsum, dres_colsum, 0);
-    HCIR_LAUNCH_CHECK();
-  }
   return HCIR_OK;
 }
 
@@ -515,8 +514,8 @@ int hcir_colsum_f16(const void* x, int64_t m, int32_t n, int64_t ldx, float* out
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hcir_cdiv(n, 256), (unsigned)chunks), dim3(256), 0, st,
                      static_cast<const _Float16*>(x), m, n, ldx, rows_per, workspace);
   HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 64), 1), dim3(256), 0, st, workspace, chunks, n,
-                     out, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 16), 1), dim3(256), 0, st, workspace, chunks, n,
+                     out, out, out, accumulate ? 1 : 0);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }
@@ -534,8 +533,8 @@ int hcir_gelu_bwd_colsum_f16(const void* u, const void* dh, int64_t m, int32_t n
                      static_cast<const _Float16*>(u), static_cast<const _Float16*>(dh), m, n, ld, rows_per,
                      static_cast<_Float16*>(du), workspace);
   HCIR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 64), 1), dim3(256), 0, st, workspace, chunks, n,
-                     colsum, colsum, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)hcir_cdiv(n, 16), 1), dim3(256), 0, st, workspace, chunks, n,
+                     colsum, colsum, colsum, accumulate ? 1 : 0);
   HCIR_LAUNCH_CHECK();
   return HCIR_OK;
 }

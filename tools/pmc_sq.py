@@ -1,7 +1,7 @@
 """Summarise `rocprofv3 --pmc <SQ counters>` passes over the training step (tools/bench_train.py) into a per-kernel
 table: matrix-pipe busy, LDS busy, bank conflicts, wait fractions.
 
-usage: python3 tools/pmc_sq.py <out.json> <pass_dir> [<pass_dir> ...]
+usage: python3 tools/pmc_sq.py <out.json> <pass_dir> [<pass_dir> ...]   |   <out.json> <earlier_summary.json>
 Each pass directory holds one rocprofv3 run (counter_collection.csv [+ kernel_trace.csv]).  SQ_* cycle counters are
 summed over the chip's SQs in quad-cycle units for the *_CYCLES family (MI355X_MICROARCH.md, counters section); only
 RATIOS of counters from the same pass are reported besides the raw per-launch averages."""
@@ -45,6 +45,12 @@ def load(d):
 def main():
     out, dirs = sys.argv[1], sys.argv[2:]
     res = collections.defaultdict(dict)
+    prior = None
+    if dirs and dirs[0].endswith(".json"):   # re-derive the fractions of an earlier summary (raw averages kept in it)
+        prior = json.load(open(dirs[0]))
+        for k, row in prior["kernels"].items():
+            res[k] = {n: v for n, v in row.items() if "frac" not in n and n != "shader_clock_ghz"}
+        dirs = []
     for d in dirs:
         for k, counters in load(d).items():
             # the largest launches of a kernel (the block-sized ones): the upper half by counter magnitude
@@ -55,11 +61,15 @@ def main():
     for k, c in res.items():
         row = {n: round(v, 1) for n, v in c.items()}
         g = c.get
-        # GRBM_GUI_ACTIVE = chip cycles of the launch (collected in every pass); 256 CUs x 4 SIMDs
-        if g("GRBM_GUI_ACTIVE") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
-            row["mfma_busy_frac_of_simd_cycles"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * g("GRBM_GUI_ACTIVE")), 4)
-        if g("GRBM_GUI_ACTIVE") and g("SQ_LDS_IDX_ACTIVE"):
-            row["lds_busy_frac_of_cu_cycles"] = round(g("SQ_LDS_IDX_ACTIVE") / (256 * g("GRBM_GUI_ACTIVE")), 4)
+        # GRBM_GUI_ACTIVE is reported SUMMED over the 8 XCDs (a 2.86 ms launch reads 47.3 M = 8 x 2.06 GHz x 2.86 ms);
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs in cycles (checked: attn_bwd2 = 32 cycles x its MFMA count)
+        cyc = g("GRBM_GUI_ACTIVE") / 8 if g("GRBM_GUI_ACTIVE") else None
+        if cyc and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+            row["mfma_busy_frac_of_simd_cycles"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * cyc), 4)
+        if cyc and g("SQ_LDS_IDX_ACTIVE"):
+            row["lds_busy_frac_of_cu_cycles"] = round(g("SQ_LDS_IDX_ACTIVE") / (256 * cyc), 4)
+        if cyc and c.get("avg_us_under_pmc"):
+            row["shader_clock_ghz"] = round(cyc / c["avg_us_under_pmc"] / 1e3, 3)
         if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY"):
             row["wait_any_frac_of_wave_cycles"] = round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 4)
         if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY"):
@@ -74,7 +84,7 @@ def main():
            "kernels": table}
     try:
         from hcir._lib import build_id
-        doc["src_hash"] = build_id()
+        doc["src_hash"] = prior["src_hash"] if prior else build_id()
     except Exception as e:  # noqa: BLE001
         doc["src_hash"] = None
         print("build id unavailable:", e)

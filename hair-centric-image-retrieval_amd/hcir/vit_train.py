@@ -245,10 +245,18 @@ class VitTrainer:
         mp = _pad64(m)
         st = torch.cuda.current_stream(dev).cuda_stream
         f32z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        # every gradient buffer is WRITTEN (accumulate=False) by the kernel that produces it: no zero fill (12 fills
+        # per block); the [mp, *] fp16 work buffers only need their pad rows m.. zero (operands of the TN GEMM)
+        f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def pad16(cols):
+            buf = torch.empty((mp, cols), dtype=torch.float16, device=dev)
+            buf[m:].zero_()
+            return buf
         grads = {}
         dres = f32z(mp, d)                                    # dL / d(residual stream), fp32
-        dy16 = torch.zeros((mp, d), dtype=torch.float16, device=dev)
-        g_flw, g_flb = f32z(d), f32z(d)
+        dy16 = pad16(d)
+        g_flw, g_flb = f32e(d), f32e(d)
         dcls16 = d_cls.detach().to(device=dev, dtype=torch.float16).contiguous()
         lastc = sv.last          # class-token-only last block: its residual gradient lives in a compact [pad64(b), d] buffer
         if lastc is None:
@@ -259,13 +267,13 @@ class VitTrainer:
             dres_c = f32z(bp, d)
             T.layernorm_bwd(lastc["x_out"], dcls16, self.fln_w, self.eps, None, dres_c, g_flw, g_flb, accumulate=False,
                             rows=b, ldx=d, ldr=d)
-        big16 = torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)     # d_h / d_u
+        big16 = pad16(self.mlp)                                                   # d_h / d_u
         # gelu(u) / LayerNorm output: recomputed per block only when the forward did not keep them
-        hbuf = None if sv.h else torch.zeros((mp, self.mlp), dtype=torch.float16, device=dev)
-        lnbuf = None if sv.ln1 else torch.zeros((mp, d), dtype=torch.float16, device=dev)
-        dqkv = torch.zeros((mp, 3 * d), dtype=torch.float16, device=dev)
-        datt = torch.zeros((mp, d), dtype=torch.float16, device=dev)
-        dln = torch.zeros((mp, d), dtype=torch.float16, device=dev)
+        hbuf = None if sv.h else pad16(self.mlp)
+        lnbuf = None if sv.ln1 else pad16(d)
+        dqkv = pad16(3 * d)
+        datt = pad16(d)
+        dln = pad16(d)
         layer_grads = []
         scale = (d // self.heads) ** -0.5
         nelem = m * d
@@ -275,7 +283,7 @@ class VitTrainer:
         fc2_b_next = None
         for li in range(len(self.lw) - 1, -1, -1):
             w = self.lw[li]
-            g = {k: f32z(*shape) for k, shape in (
+            g = {k: f32e(*shape) for k, shape in (
                 ("ln1_w", (d,)), ("ln1_b", (d,)), ("qkv_w", (3 * d, d)), ("qkv_b", (3 * d,)), ("proj_w", (d, d)),
                 ("proj_b", (d,)), ("ln2_w", (d,)), ("ln2_b", (d,)), ("fc1_w", (self.mlp, d)), ("fc1_b", (self.mlp,)),
                 ("fc2_w", (d, self.mlp)), ("fc2_b", (d,)))}
@@ -307,7 +315,7 @@ class VitTrainer:
                     self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
                 T.gemm_tn(dqkv, lncur, g["qkv_w"], accumulate=False)
                 T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
-                fc2_b_next = f32z(d) if li > 0 else None
+                fc2_b_next = f32e(d) if li > 0 else None
                 T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
                                 accumulate=False, rows=m, dres16=dy16 if li > 0 else None, dres_colsum=fc2_b_next)
                 layer_grads.append(g)
@@ -347,7 +355,7 @@ class VitTrainer:
                 self._ln(sv.x_in[li], m, d, d, w["ln1_w"], w["ln1_b"], lnbuf, st)
             T.gemm_tn(dqkv, lncur, g["qkv_w"], accumulate=False)
             T.colsum(dqkv, g["qkv_b"], accumulate=False, rows=m)
-            fc2_b_next = f32z(d) if li > 0 else None
+            fc2_b_next = f32e(d) if li > 0 else None
             T.layernorm_bwd(sv.x_in[li], dln, w["ln1_w"], self.eps, dres, dres, g["ln1_w"], g["ln1_b"],
                             accumulate=False, rows=m, dres16=dy16 if li > 0 else None, dres_colsum=fc2_b_next)
             layer_grads.append(g)
@@ -359,8 +367,8 @@ class VitTrainer:
         npat = b * (t - 1)
         dpatch = torch.zeros((_pad64(npat), d), dtype=torch.float16, device=dev)
         dpatch[:npat] = dtok[:, 1:].reshape(npat, d)
-        g_cw = f32z(d, sv.patches.shape[1])
-        g_cb = f32z(d)
+        g_cw = f32e(d, sv.patches.shape[1])
+        g_cb = f32e(d)
         T.gemm_tn(dpatch, sv.patches, g_cw, accumulate=False)
         T.colsum(dpatch, g_cb, accumulate=False, rows=npat)
         s = self.spec

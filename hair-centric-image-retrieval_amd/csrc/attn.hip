@@ -129,39 +129,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mxs = mx * a.scale_log2e;
     float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][i], a.scale_log2e, -mxs));
-        sc[kt][i] = p;
-        sum += p;
-      }
-    }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    if (a.lse && h == 0 && q0 + r < a.nq)   // p = exp2(s * scale_log2e - lse): what hcir_attn_bwd recomputes P from
-      a.lse[(b * a.h + head) * (int64_t)a.t + q0 + r] = mxs + __builtin_amdgcn_logf(sum);
-
-    // ---- O^T = V^T . P ----
+    // ---- P = exp2(S scale log2e - max), O^T = V^T . P, software-pipelined over the key tiles: the exponentials of
+    //      key tile kt + 1 stand between the transposed V reads and the MFMAs of key tile kt IN ONE BASIC BLOCK (the
+    //      lse store, a branch, moved behind the loop), so the 16 x (fma, v_exp_f32, add) chains issue in the shadow
+    //      of the matrix pipe.  As one block of 112 v_exp_f32 in front of the PV MFMAs (what hipcc emitted for the
+    //      plain loop nest) the wave's matrix pipe idled for ~1800 cycles per query tile.
+#define HCIR_EXP_TILE(KT)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                    \
+    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[KT][i], a.scale_log2e, -mxs));           \
+    sc[KT][i] = p;                                                                                    \
+    sum += p;                                                                                         \
+  }
     f32x16 oacc[2];
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
       for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
+    HCIR_EXP_TILE(0)
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
+      f16x8 pf[2], vf[2][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        f16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (_Float16)sc[kt][8 * s + j];
+        for (int j = 0; j < 8; ++j) pf[s][j] = (_Float16)sc[kt][8 * s + j];
 #pragma unroll
         for (int hdt = 0; hdt < 2; ++hdt) {
           // transposed read: this lane supplies row (kb + li>>2), columns c0 + 4*(li&3) .. +3
           const int c0 = 32 * hdt + 16 * (grp & 1) + 4 * (li & 3);
           const int kb = 32 * kt + 16 * s + 4 * (grp >> 1) + (li >> 2);
-          f16x8 vf;
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int key = kb + 8 * half;
@@ -169,12 +165,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
                 (fp16x4_t __attribute__((address_space(3)))*)(vsl + key * 128 + col * 2));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vf[4 * half + e] = (_Float16)v4[e];
+            for (int e = 0; e < 4; ++e) vf[s][hdt][4 * half + e] = (_Float16)v4[e];
           }
-          oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[hdt], 0, 0, 0);
         }
       }
+      if (kt + 1 < NKT) {
+        HCIR_EXP_TILE(kt + 1)
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int hdt = 0; hdt < 2; ++hdt)
+          oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s][hdt], pf[s], oacc[hdt], 0, 0, 0);
+#ifdef HCIR_ATTN_SGB   // build flag (A/B): force one MFMA per 12 VALU of the neighbouring exponentials
+      if (kt + 1 < NKT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+        }
+      }
+#endif
     }
+#undef HCIR_EXP_TILE
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (a.lse && h == 0 && q0 + r < a.nq)   // p = exp2(s * scale_log2e - lse): what hcir_attn_bwd recomputes P from
+      a.lse[(b * a.h + head) * (int64_t)a.t + q0 + r] = mxs + __builtin_amdgcn_logf(sum);
 
     // ---- store: the lane owns query row q0 + r and 4-dim pieces of it; a direct store would write 16 B of 32
     //      different rows per instruction (partial lines).  The wave transposes its 32 x 64 tile through 4 KB of

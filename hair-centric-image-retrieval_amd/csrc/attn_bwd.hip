@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
   const int myrow_c = myrow < a.t ? myrow : a.t - 1;
   const bool live = myrow < a.t;
   const uint32_t lds0 = lds_addr(lds);
+  const float inv_c = 1.0f / a.scale_log2e;
 
   // One image = 4 nw wave instructions of 8 rows; piece u (0..3) of wave w is instruction w + u nw.  Rows past T
   // fetch the last real row: finite data; P is exactly 0 there through lse = +inf (queries) or the key mask.
@@ -432,7 +433,13 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
     const _Float16* kgl = a.qkv + qb + (int64_t)a.h * 64;
     const _Float16* vgl = kgl + (int64_t)a.h * 64;
     AB2_STAMP(0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // R0 of this item has landed (issued under the previous pass 2)
+    // R0 of this item has landed (issued under the first tiles of the previous pass 2).  The eight dK / dV row stores
+    // of that pass were issued BEHIND the transfers (vmcnt retires in order): they may stay in flight - waiting for
+    // their acknowledgements cost ~4 k cycles per item.
+    if (prev < 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // the fragments / lse prefetched with it have landed too: take them out of the compiler's pending set, or it
     // re-waits (vmcnt(0)) at their first use, behind the K / V transfer issued below
     asm volatile("" : "+v"(lv));
@@ -462,9 +469,9 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
         }
       }
       dsv += __shfl_xor(dsv, 1);
-      if ((tid & 1) == 0) {
-        dsum[drow] = dsv;
-        lrow[drow] = lv;
+      if ((tid & 1) == 0) {   // stored as the accumulator start values of pass 1: -D and -lse / (scale log2e)
+        dsum[drow] = -dsv;
+        lrow[drow] = -lv * inv_c;   // lse = +inf past T: -inf, so P = exp2(-inf) = 0 there
       }
     }
     __syncthreads();
@@ -487,38 +494,45 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
           dma_piece(vs, vgl, qkv_stride, u);
         }
       const int q0 = qt * 32;
+      // Issue order is pinned with sched_barriers: left to itself hipcc fetched the row constants and the transposed
+      // A operands just in time, into the same eight registers, and every pair of dV / dK MFMAs waited out an LDS
+      // round trip (pass 1 without that MFMA group: 7.4 k cycles instead of 13.7 k, 2 x the group's pipe time).
+      // ---- all row reads of the tile: Q / dO fragments, then lse / D of the 16 accumulator rows
       f16x8 qf[4], dof[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         qf[s] = *reinterpret_cast<const f16x8*>(qs + img2_off(q0 + r, 2 * s + h));
         dof[s] = *reinterpret_cast<const f16x8*>(dos + img2_off(q0 + r, 2 * s + h));
       }
+      // the accumulators START from the row constants: sc = -lse / (scale log2e), dp = -D (both stored that way by
+      // the D phase), so that the MFMAs leave S - lse / c and dP - D: no per-element subtraction, no constants live
+      // beside the accumulators (rows q0 + 8 g + 4 h .. + 3 = accumulator registers 4 g .. 4 g + 3)
       f32x16 sc, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sc[i] = dp[i] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lrow + q0 + 8 * g + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dsum + q0 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sc[4 * g + e] = l4[e];
+          dp[4 * g + e] = d4[e];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(qf[s], kf[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(dof[s], vf[s], dp, 0, 0, 0);
       }
-      f16x8 pf[2], dsf[2];   // [16-query k-step], accumulator-operand k order
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float lq = lrow[q0 + acc_row(i, h)], dq = dsum[q0 + acc_row(i, h)];
-        // keys past T (this lane's column) need no mask here: they only reach dK^T / dV^T columns that are never stored
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], a.scale_log2e, -lq));
-        pf[i >> 3][i & 7] = (_Float16)p;
-        dsf[i >> 3][i & 7] = (_Float16)(p * (dp[i] - dq));
-      }
-      // dV^T += dO^T P, dK^T += Q^T dS: A operands by transposed reads; element j of half h is query
-      // 16 s + 8 (j >> 2) + 4 h + (j & 3)
+      // ---- the transposed A operands of dV^T += dO^T P, dK^T += Q^T dS, in flight under the exp chain below
+      //      (element j of half h is query 16 s + 8 (j >> 2) + 4 h + (j & 3))
+      f16x8 dotf[2][2], qtff[2][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int c0 = 32 * dt + 16 * (grp & 1) + 4 * (li & 3);
           const int qrow = q0 + 16 * s + 4 * (grp >> 1) + (li >> 2);
-          f16x8 dot, qtf;
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const ab_fp16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -527,14 +541,31 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
                 (ab_fp16x4 __attribute__((address_space(3)))*)(qs + img2_off_e(qrow + 8 * half, c0)));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              dot[4 * half + e] = (_Float16)v1[e];
-              qtf[4 * half + e] = (_Float16)v2[e];
+              dotf[s][dt][4 * half + e] = (_Float16)v1[e];
+              qtff[s][dt][4 * half + e] = (_Float16)v2[e];
             }
           }
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dot, pf[s], dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtf, dsf[s], dkt[dt], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 pf[2], dsf[2];   // [16-query k-step], accumulator-operand k order
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        // keys past T (this lane's column) need no mask here: they only reach dK^T / dV^T columns that are never stored
+        const float p = __builtin_amdgcn_exp2f(sc[i] * a.scale_log2e);
+        pf[i >> 3][i & 7] = (_Float16)p;
+        dsf[i >> 3][i & 7] = (_Float16)(p * dp[i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dotf[s][dt], pf[s], dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtff[s][dt], dsf[s], dkt[dt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     AB2_STAMP(3)
     // Q / dO rows of this wave's QUERIES (B operands of pass 2) and their row constants, while R0 is still this item's
@@ -544,7 +575,7 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
       qb2[s] = *reinterpret_cast<const f16x8*>(qs + img2_off(myrow, 2 * s + h));
       dob2[s] = *reinterpret_cast<const f16x8*>(dos + img2_off(myrow, 2 * s + h));
     }
-    const float lq2 = lrow[myrow], dq2 = dsum[myrow];
+    const float lq2 = -lrow[myrow] * a.scale_log2e, dq2 = -dsum[myrow];   // back to lse and D (pass 2 subtracts them)
     // dK = scale dK^T, dV = dV^T: lane = key, registers = dims; packed now, stored under pass 2
     u32x4 dko[4], dvo[4];
     pack_rows(dkt, a.scale, dko);
@@ -581,12 +612,14 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
           store_chunk(a.dqkv + qb + (int64_t)2 * a.h * 64, c, dvo[c]);
         }
       const int k0 = kt * 32;
+      __builtin_amdgcn_sched_barrier(0);
       f16x8 ka[4], va[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         ka[s] = *reinterpret_cast<const f16x8*>(ks + img2_off(k0 + r, 2 * s + h));
         va[s] = *reinterpret_cast<const f16x8*>(vs + img2_off(k0 + r, 2 * s + h));
       }
+      __builtin_amdgcn_sched_barrier(0);
       f32x16 st, dpt;
 #pragma unroll
       for (int i = 0; i < 16; ++i) st[i] = dpt[i] = 0.f;
@@ -595,6 +628,24 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
         st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[s], qb2[s], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[s], dob2[s], dpt, 0, 0, 0);
       }
+      // K^T fragments of dQ^T += K^T dS^T (accumulator operand's k order), in flight under the exp chain
+      f16x8 ktf[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int c0 = 32 * dt + 16 * (grp & 1) + 4 * (li & 3);
+          const int krow = k0 + 16 * s + 4 * (grp >> 1) + (li >> 2);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const ab_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (ab_fp16x4 __attribute__((address_space(3)))*)(ks + img2_off_e(krow + 8 * half, c0)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ktf[s][dt][4 * half + e] = (_Float16)v[e];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f16x8 dsb[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -602,24 +653,13 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
         if (decltype(masked)::value) p = k0 + acc_row(i, h) < a.t ? p : 0.f;   // keys past T: the last tile only
         dsb[i >> 3][i & 7] = (_Float16)(p * (dpt[i] - dq2));
       }
-      // dQ^T += K^T dS^T: A operand by transposed reads of the K image in the accumulator operand's k order
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int c0 = 32 * dt + 16 * (grp & 1) + 4 * (li & 3);
-          const int krow = k0 + 16 * s + 4 * (grp >> 1) + (li >> 2);
-          f16x8 ktf;
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const ab_fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                (ab_fp16x4 __attribute__((address_space(3)))*)(ks + img2_off_e(krow + 8 * half, c0)));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ktf[4 * half + e] = (_Float16)v[e];
-          }
-          dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf, dsb[s], dqa[dt], 0, 0, 0);
-        }
-      }
+        for (int dt = 0; dt < 2; ++dt)
+          dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf[s][dt], dsb[s], dqa[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     };
     for (int kt = 0; kt + 1 < nw; ++kt) key_tile(kt, std::false_type{});
     key_tile(nw - 1, std::true_type{});

@@ -13,7 +13,8 @@ objs=""
 for o in "$src"/*.o; do
   b=$(basename "$o" .o)
   if echo " $files " | grep -q " $b.hip "; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function $flags -c "$src/$b.hip" -o "$tmp/$b.o"
+    extra=""; [ "$b" = attn_bwd ] && extra="-fno-slp-vectorize"   # as in csrc/Makefile
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function $extra $flags -c "$src/$b.hip" -o "$tmp/$b.o"
     objs="$objs $tmp/$b.o"
   else
     objs="$objs $o"

@@ -23,19 +23,20 @@ lse = torch.empty(b, h, t, device="cuda", dtype=torch.float32)
 dqkv = torch.empty_like(qkv)
 st = torch.cuda.current_stream().cuda_stream
 assert L.hcir_attn_fwd_lse(qkv.data_ptr(), b, t, h, 64, 0.125, out.data_ptr(), lse.data_ptr(), st) == 0
-names = ["loop top -> R0 landed + barrier", "dQ(prev) stores, K/V DMA issue, D, barrier", "pass 1 (7 query tiles)",
-         "pass-2 operands, R1 landed + barrier", "dK/dV stores + next item's prefetch issue", "pass 2 (7 key tiles)"]
+names = ["loop top -> R0 landed + barrier", "dQ(prev) stores, D, barrier", "pass 1 (7 query tiles, K/V transfers inside)",
+         "pass-2 operands, dK/dV packing, R1 landed + barrier", "pass 2 (7 key tiles; stores, next R0 inside)"]
+idx = [0, 1, 2, 3, 4, 6]
 for rep in range(4):
     assert L.hcir_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), b, t, h, 64, 0.125,
                            dqkv.data_ptr(), st) == 0
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 16)()
     assert L.hcir_diag_attn_bwd_stamps(buf) == 0
-    cyc = [buf[2 * i] for i in range(7)]
-    rt = [buf[2 * i + 1] for i in range(7)]
+    cyc = [buf[2 * i] for i in idx]
+    rt = [buf[2 * i + 1] for i in idx]
     if rep < 2:
         continue
-    tot_c, tot_us = cyc[6] - cyc[0], (rt[6] - rt[0]) / 100.0
+    tot_c, tot_us = cyc[-1] - cyc[0], (rt[-1] - rt[0]) / 100.0
     print(f"run {rep}: item {tot_c} cycles = {tot_us:.2f} us  ({tot_c / max(tot_us, 1e-9) / 1e3:.2f} GHz)")
     for i, n in enumerate(names):
-        print(f"   {n:50s} {cyc[i + 1] - cyc[i]:7d} cycles")
+        print(f"   {n:58s} {cyc[i + 1] - cyc[i]:7d} cycles")

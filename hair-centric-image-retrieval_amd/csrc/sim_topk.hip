@@ -1824,6 +1824,10 @@ int hcir_sim_topk(const void* q, int64_t nq, const void* g, int64_t ng, int32_t 
 
   Plan pp = p;  // (the prefix may shrink below)
   if (cand_prefix) pp.prefix = cand_prefix;
+  // Group-floor candidate flow (k > 16): its fallback (a candidate buffer overflowed, ~1e-5 per call) is the ONE-phase
+  // list scan over all rows + one merge - two gated launches that exit at once in the common case, where the
+  // two-phase flow cost four (~4.5 us each even when empty: 3 % of a 64-query C5 call).
+  if (fallback_gate && !prefix_done) pp.prefix = ng;
   // Many queries (MFMA-bound): the 256 x 256 tile scan collects the rare rows above the prefix floor.  The
   // prefix itself runs on the list-keeping kernel at half that rate, so it is only as long as the candidate
   // buffers require.  With r = rows behind the prefix / prefix rows, the number of rows that beat the

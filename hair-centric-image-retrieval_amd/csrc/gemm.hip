@@ -610,6 +610,11 @@ __device__ unsigned long long g_gemm_stamps[256 * 8];
 #ifndef HCIR_GEMM_NGROUP
 #define HCIR_GEMM_NGROUP 3  // tools/ab_gemm.py, batch 880: fc1 908 -> 890 us, qkv 574 -> 568 us (0 = n fastest over the whole N)
 #endif
+#ifndef HCIR_GEMM_NGROUP_WIDE
+#define HCIR_GEMM_NGROUP_WIDE 6  // group size when it divides tiles_n (fc1: 12 n-tiles): the activation panels are
+                                 // then fetched by two XCD sets instead of four (PMC: fc1 reads x5.3 -> see DESIGN);
+                                 // time flat against 3 (profiles/r3_diag_ab_gemm_ngroup.txt), fabric bytes -20 %
+#endif
 
 struct G256 {
   static constexpr int NT = 512;
@@ -637,11 +642,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     // n-grouped order: the W panels of one group of HCIR_GEMM_NGROUP n-tiles stay in the XCD's L2 while every
     // m-tile streams past them (a W set wider than the 4 MB L2 - fc1: 12 panels, 4.7 MB - is otherwise re-fetched
     // for every row of tiles)
-    if (tiles_n % HCIR_GEMM_NGROUP == 0 && tiles_n > HCIR_GEMM_NGROUP) {
-      const int per = HCIR_GEMM_NGROUP * tiles_m;
+    const int ngrp = (HCIR_GEMM_NGROUP_WIDE > 0 && tiles_n % HCIR_GEMM_NGROUP_WIDE == 0 && tiles_n > HCIR_GEMM_NGROUP_WIDE)
+                         ? HCIR_GEMM_NGROUP_WIDE : HCIR_GEMM_NGROUP;
+    if (tiles_n % ngrp == 0 && tiles_n > ngrp) {
+      const int per = ngrp * tiles_m;
       const int grp = t / per, rem = t - grp * per;
-      n0 = (grp * HCIR_GEMM_NGROUP + rem % HCIR_GEMM_NGROUP) * 256;
-      m0 = (int64_t)(rem / HCIR_GEMM_NGROUP) * 256;
+      n0 = (grp * ngrp + rem % ngrp) * 256;
+      m0 = (int64_t)(rem / ngrp) * 256;
       return;
     }
 #endif

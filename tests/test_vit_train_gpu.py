@@ -142,6 +142,35 @@ def test_forward_views_equals_separate_calls():
             assert _rel(b2, b1) <= 1e-2, n1
 
 
+@pytest.mark.parametrize("kwargs", [dict(keep_recomputable=False), dict(cls_only_last=False),
+                                    dict(keep_recomputable=False, cls_only_last=False)])
+def test_trainer_variants_match_default(kwargs):
+    """`keep_recomputable=False` (LayerNorm outputs and gelu(u) recomputed in the backward instead of kept: 11.8 instead
+    of 15.4 KB per token and block) and `cls_only_last=False` (the last block on every token) against the default
+    trainer: same class-token output, every gradient within the fp16 rounding the different operand paths leave
+    (gelu recomputed from the fp16 pre-activation instead of the fp32 accumulator: one fp16 ulp on h)."""
+    import copy
+    from hcir.main_backbone import SHAM2
+    from hcir.vit_train import VitTrainer
+    torch.manual_seed(21)
+    m1 = SHAM2("vit_b_16").cuda().train()
+    _perturb(m1, 3)
+    m2 = copy.deepcopy(m1)
+    dev = torch.device("cuda")
+    m2.backbone._trainer = VitTrainer(m2.backbone._spec(), dev, **kwargs)
+    x = torch.randn(3, 3, 224, 224, device="cuda")
+    wgt = torch.randn(3, 768, device="cuda")
+    c1 = m1.backbone.forward_cls(x)
+    c2 = m2.backbone.forward_cls(x)
+    assert _rel(c2.detach(), c1.detach()) <= 2e-3
+    (c1 * wgt).sum().backward()
+    (c2 * wgt).sum().backward()
+    for (n, p1), (_, p2) in zip(m1.backbone.named_parameters(), m2.backbone.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), n
+        if p1.grad is not None:
+            assert _rel(p2.grad, p1.grad) <= 1e-2, (n, _rel(p2.grad, p1.grad))
+
+
 def test_vit_backward_gradient_direction_decreases_loss():
     """Independent of any oracle: a small step against the HIP gradient lowers the loss by ~ lr |g|^2."""
     from hcir.main_backbone import SHAM2

@@ -1381,6 +1381,17 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
 #endif
   const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
   const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
+#if !defined(HCIR_GEMM_NO_MID_SMALL) && !defined(HCIR_GEMM_MFMA32)
+  // Small M: a launch whose 256 x 256 tiles fill less than 0.7 of ONE round of the 256 CUs (64 images: proj / fc2 give
+  // 150 tiles) runs on the 128 x 192 kernel at two workgroups per CU instead - 2.7 x the tiles, every CU busy; its
+  // results are bit-identical (same k order).  12 % slower per flop on full rounds, which is why only these take it.
+  if constexpr (EPI != EPI_BIAS_F16_DUAL_GELU) {
+    if (tn * tm * 10 < 256 * 7 && g.n % GMid::TN == 0 && (g.n / GMid::TN) * hcir_cdiv(g.m, GMid::TM) <= 512) {
+      launch_gemm_mid<EPI>(g, st);
+      return;
+    }
+  }
+#endif
   // MFMA shape: a BUILD flag (make CXXFLAGS+=-DHCIR_GEMM_MFMA32 builds the 32x32x16 variant for A/B runs through
   // HCIR_LIB_PATH); the library reads no environment variables
 #ifdef HCIR_GEMM_MFMA32

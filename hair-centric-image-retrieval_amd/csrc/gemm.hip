@@ -45,6 +45,7 @@ struct GemmArgs {
   float* stats_part;      // [n/64][m][2] partial (sum, sumsq) of out rows (EPI_RESID_F16_STATS)
   const void* resid;      // residual rows of the *_RESID_* epilogues (same type and row pitch as out); == out: in place
   void* out2;             // second fp16 output of EPI_BIAS_F16_DUAL_GELU (row pitch ldo)
+  int64_t stats_ld = 0;   // rows per slice of stats_part (0: m) - a launch over a row range of a larger matrix
 };
 
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8
@@ -460,7 +461,7 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
             m2 = sum8_dpp(m2);
             if (rchunk == 0 && (FULL || m < g.m)) {
               const int64_t slice = (nbase >> 6) + pass;
-              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){mean_s, m2};
+              *reinterpret_cast<f32x2*>(g.stats_part + (slice * (g.stats_ld ? g.stats_ld : g.m) + m) * 2) = (f32x2){mean_s, m2};
             }
           }
         }
@@ -999,7 +1000,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
             m2 = sum8_dpp(m2);
             if (rchunk == 0 && (FULL || m < g.m)) {
               const int64_t slice = (nbase >> 6) + pass;
-              *reinterpret_cast<f32x2*>(g.stats_part + (slice * g.m + m) * 2) = (f32x2){mean_s, m2};
+              *reinterpret_cast<f32x2*>(g.stats_part + (slice * (g.stats_ld ? g.stats_ld : g.m) + m) * 2) = (f32x2){mean_s, m2};
             }
           }
         }
@@ -1381,6 +1382,37 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
 #endif
   const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
   const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
+#if !defined(HCIR_GEMM_NO_TAIL_SPLIT) && !defined(HCIR_GEMM_MFMA32)
+  // Tail split: when the last round of 256 x 256 tiles would be less than half full (64 images: fc1 = 600 tiles = 2.34
+  // rounds; ViT-L/14 at 128 images: 516 / 1548 / 2064 tiles = 2.02 / 6.05 / 8.06 rounds - a whole round for a sliver),
+  // the m-tiles that fill whole rounds run here and the remaining ROWS go to the 128 x 192 kernel as a second launch
+  // (pointers advanced to the row range; the per-row statistics keep the full matrix's slice pitch).
+  if constexpr (EPI != EPI_BIAS_F16_DUAL_GELU) {
+    const int ntiles = tn * tm;
+    const int tm1 = (ntiles / 256) * 256 / tn;          // m-tiles of the whole rounds
+    const int tail_tiles = ntiles - tm1 * tn;
+    const int64_t m1 = (int64_t)tm1 * 256;
+    if (ntiles > 256 && tm1 > 0 && tm1 < tm && tail_tiles < 128 && g.n % GMid::TN == 0 &&
+        (g.n / GMid::TN) * hcir_cdiv(g.m - m1, GMid::TM) <= 512) {
+      GemmArgs g1 = g, g2 = g;
+      g1.m = m1;
+      g1.stats_ld = g.stats_ld ? g.stats_ld : g.m;
+      g2.m = g.m - m1;
+      g2.stats_ld = g1.stats_ld;
+      g2.a = g.a + m1 * g.lda;
+      const bool f32out = EPI == HCIR_EPI_BIAS_RESID_F32 || EPI == HCIR_EPI_BIAS_F32 || EPI == HCIR_EPI_AFFINE_F32;
+      const int64_t obytes = m1 * g.ldo * (f32out ? 4 : 2);
+      g2.out = static_cast<char*>(g.out) + obytes;
+      if (g.resid) g2.resid = static_cast<const char*>(g.resid) + obytes;
+      if (g.ln_stats) g2.ln_stats = g.ln_stats + 2 * m1;
+      if (g.stats_part) g2.stats_part = g.stats_part + 2 * m1;
+      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(tm1 * tn < 256 ? tm1 * tn : 256), dim3(512), 0, st, g1, tn,
+                         tm1);
+      launch_gemm_mid<EPI>(g2, st);
+      return;
+    }
+  }
+#endif
 #if !defined(HCIR_GEMM_NO_MID_SMALL) && !defined(HCIR_GEMM_MFMA32)
   // Small M: a launch whose 256 x 256 tiles fill less than 0.7 of ONE round of the 256 CUs (64 images: proj / fc2 give
   // 150 tiles) runs on the 128 x 192 kernel at two workgroups per CU instead - 2.7 x the tiles, every CU busy; its

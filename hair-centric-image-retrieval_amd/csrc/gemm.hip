@@ -668,9 +668,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     tile_origin(t_i, n0, m0);
     wbase = reinterpret_cast<const char*>(g.w + (int64_t)n0 * g.ldw);
     abase = reinterpret_cast<const char*>(g.a + m0 * g.lda);
+    // opaque thread id: the per-piece row / chunk values below are cheap to recompute once per tile; hoisted out of
+    // the tile loop they stayed live through the main loop (and were SPILLED in the dual-output variant, whose
+    // per-tile reload then waited - vmcnt(0) - for the stage in flight)
+    int otid = tid;
+    asm volatile("" : "+v"(otid));
 #pragma unroll
     for (int i = 0; i < G256::NLOAD; ++i) {
-      const int piece = tid + G256::NT * i;
+      const int piece = otid + G256::NT * i;
       const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
       if (row < 256) {
         const int nr = n0 + row > g.n - 1 ? g.n - 1 - n0 : row;
@@ -809,6 +814,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       acc.zero();
       kc = 0;
       ++ti;
+      // the DMA source offsets of the tile being issued are RE-DERIVED here instead of living through the epilogue:
+      // the dual-output variant spilled them, and its reload made the compiler put vmcnt(0) in front of every DMA
+      // group of the main loop (MFMA busy 39 % against 57 % for the other variants)
+      if (issue_ti < my_tiles) set_sources(issue_ti);
     }
   }
 }

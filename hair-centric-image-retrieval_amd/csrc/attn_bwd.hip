@@ -364,7 +364,12 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
     const int src = row < a.t ? row : a.t - 1;
     lds_dma16(g, (uint32_t)(src * stride * 2 + ((pc ^ swz2(row)) << 4)), lds0 + (uint32_t)(img - lds) + ii * 1024);
   };
-  auto piece_tile = [&](int u) { return u < nw - 1 ? u : nw - 1; };
+#if defined(HCIR_AB2_ABL) && HCIR_AB2_ABL == 5   // timing ablation (wrong results): one tile per pass, all memory traffic
+  const int nwl = 1;
+#else
+  const int nwl = nw;
+#endif
+  auto piece_tile = [&](int u) { return u < nwl - 1 ? u : nwl - 1; };
   auto qkv_base = [&](int item) { return ((int64_t)(item / a.h) * a.t) * qkv_stride + (item % a.h) * 64; };
   auto o_base = [&](int item) { return ((int64_t)(item / a.h) * a.t) * o_stride + (item % a.h) * 64; };
   auto issue_r0 = [&](int item, int u) {
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
     for (int x = 0; x < 2; ++x)
 #pragma unroll
       for (int i = 0; i < 16; ++i) dkt[x][i] = dvt[x][i] = 0.f;
-    for (int qt = 0; qt < nw; ++qt) {
+    for (int qt = 0; qt < nwl; ++qt) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (piece_tile(u) == qt) {
@@ -549,21 +554,48 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
       }
       __builtin_amdgcn_sched_barrier(0);
       f16x8 pf[2], dsf[2];   // [16-query k-step], accumulator-operand k order
+      // (keys past T - this lane's column - need no mask here: they only reach dK^T / dV^T columns that are never stored)
+      // (-DHCIR_AB2_HALVES: the exp chain of the second 16-query k-step issued in the shadow of the first k-step's four
+      // MFMAs - measured 2659 against 2662 us per launch, i.e. nothing: the two waves of a SIMD already cover each
+      // other's phases; the plain order is what ships)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // keys past T (this lane's column) need no mask here: they only reach dK^T / dV^T columns that are never stored
+      for (int i = 0; i < 8; ++i) {
         const float p = __builtin_amdgcn_exp2f(sc[i] * a.scale_log2e);
-        pf[i >> 3][i & 7] = (_Float16)p;
-        dsf[i >> 3][i & 7] = (_Float16)(p * dp[i]);
+        pf[0][i] = (_Float16)p;
+        dsf[0][i] = (_Float16)(p * dp[i]);
       }
+#ifndef HCIR_AB2_HALVES
+#pragma unroll
+      for (int i = 8; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sc[i] * a.scale_log2e);
+        pf[1][i & 7] = (_Float16)p;
+        dsf[1][i & 7] = (_Float16)(p * dp[i]);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int dt = 0; dt < 2; ++dt) {
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dotf[0][dt], pf[0], dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtff[0][dt], dsf[0], dkt[dt], 0, 0, 0);
+      }
+#ifdef HCIR_AB2_HALVES
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dotf[s][dt], pf[s], dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtff[s][dt], dsf[s], dkt[dt], 0, 0, 0);
-        }
+      for (int i = 8; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sc[i] * a.scale_log2e);
+        pf[1][i & 7] = (_Float16)p;
+        dsf[1][i & 7] = (_Float16)(p * dp[i]);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {   // one MFMA, then a quarter of the chain (8 x (mul, exp, mul) + 8 cvt = 32 VALU)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dotf[1][dt], pf[1], dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qtff[1][dt], dsf[1], dkt[dt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -661,8 +693,8 @@ __global__ __launch_bounds__(64 * kNW2, 1) void attn_bwd2_kernel(AttnBwdArgs a, 
           dqa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ktf[s][dt], dsb[s], dqa[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kt = 0; kt + 1 < nw; ++kt) key_tile(kt, std::false_type{});
-    key_tile(nw - 1, std::true_type{});
+    for (int kt = 0; kt + 1 < nwl; ++kt) key_tile(kt, std::false_type{});
+    key_tile(nwl - 1, std::true_type{});
     pack_rows(dqa, a.scale, dqo);   // dQ = scale dQ^T: lane = query
     AB2_STAMP(6)
     prev = item;

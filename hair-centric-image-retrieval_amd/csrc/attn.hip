@@ -99,9 +99,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (qt + 4 < nqt) load_q(qt + 4, qn);
 
     // ---- S^T = K . Q^T ----
+#ifdef HCIR_ATTN_ABL   // timing ablation (wrong results): one key tile of compute, all memory traffic
+    constexpr int NKC = 1;
+#else
+    constexpr int NKC = NKT;
+#endif
     f32x16 sc[NKT];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKC; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
       const int key = kt * 32 + r;
@@ -119,11 +124,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float mx = ninf;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int key = (NKT - 1) * 32 + acc_row(i, h);
-      sc[NKT - 1][i] = key < a.t ? sc[NKT - 1][i] : ninf;
+      const int key = (NKC - 1) * 32 + acc_row(i, h);
+      sc[NKC - 1][i] = key < a.t ? sc[NKC - 1][i] : ninf;
     }
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = 0; kt < NKC; ++kt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
     HCIR_EXP_TILE(0)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NKC; ++kt) {
       f16x8 pf[2], vf[2][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           }
         }
       }
-      if (kt + 1 < NKT) {
+      if (kt + 1 < NKC) {
         HCIR_EXP_TILE(kt + 1)
       }
 #pragma unroll
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int hdt = 0; hdt < 2; ++hdt)
           oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s][hdt], pf[s], oacc[hdt], 0, 0, 0);
 #ifdef HCIR_ATTN_SGB   // build flag (A/B): force one MFMA per 12 VALU of the neighbouring exponentials
-      if (kt + 1 < NKT) {
+      if (kt + 1 < NKC) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -237,6 +242,186 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+  }
+}
+
+// --------------------------------------------------------------------------
+// T in (192, 224] (ViT-B/16: 197 tokens), all query rows: PERSISTENT workgroup of seven waves, wave w owns query tile
+// w of every (b, head) item the workgroup walks over; two K / V image pairs in LDS, the next item's pair filled by
+// LDS-DMA (lds_dma16: invisible to hipcc, see common.h) and the next item's Q fragments requested while the current
+// item computes; one barrier per item.  The 4-wave kernel above loads, computes and stores in sequence and relies on
+// its second co-resident workgroup for overlap: with one key tile of compute it takes 197 us per launch at 880 images
+// (all bytes moved), with all seven 286 us - 89 us of compute standing outside the memory time.  (Round 2's persistent
+// attempt gained 2.5 %: its pending transfers were retired by the compiler in front of every transposed V read.)
+// Same S / softmax / PV code, same LDS images, same results as attn_fwd_kernel<7>.
+// --------------------------------------------------------------------------
+constexpr int kF2NKT = 7, kF2Rows = 32 * kF2NKT, kF2Img = kF2Rows * 128;
+
+__global__ __launch_bounds__(64 * kF2NKT, 1) void attn_fwd2_kernel(AttnArgs a, int items) {
+  constexpr int NKT = kF2NKT;
+  __shared__ __attribute__((aligned(16))) char lds[4 * kF2Img + kF2NKT * 4096];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int grp = lane >> 4, li = lane & 15;
+  const int row_stride = 3 * a.h * 64;   // elements between tokens
+  const uint32_t lds0 = lds_addr(lds);
+  const float ninf = -__builtin_huge_valf();
+  const int q0 = wave * 32;
+  const bool active = q0 < a.nq;                 // this wave's query tile exists
+  auto item_base = [&](int item) { return ((int64_t)(item / a.h) * a.t) * row_stride + (item % a.h) * 64; };
+
+  // K / V images of `item` into buffer `buf`: 2 x 28 wave instructions of 8 rows, four of each per wave
+  auto dma_kv = [&](int item, int buf) {
+    const _Float16* kg = a.qkv + item_base(item) + (int64_t)a.h * 64;
+    const _Float16* vg = kg + (int64_t)a.h * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ii = wave + u * NKT;
+      const int key = ii * 8 + (lane >> 3), pc = lane & 7;
+      const int src = key < a.t ? key : a.t - 1;   // past T: the last real key (finite; masked / P = 0)
+      const uint32_t rowoff = (uint32_t)(src * row_stride * 2);
+      lds_dma16(kg, rowoff + ((pc ^ ((key >> 1) & 7)) << 4), lds0 + buf * 2 * kF2Img + ii * 1024);
+      lds_dma16(vg, rowoff + ((pc ^ (((key >> 1) & 1) << 2)) << 4), lds0 + buf * 2 * kF2Img + kF2Img + ii * 1024);
+    }
+  };
+  f16x8 qf[4], qn[4];
+  auto load_q = [&](int item, f16x8 (&dst)[4]) {
+    int qrow = q0 + r;
+    qrow = qrow < a.t ? qrow : a.t - 1;
+    const char* qg = reinterpret_cast<const char*>(a.qkv + item_base(item));
+    const uint32_t off = (uint32_t)(qrow * row_stride * 2 + 16 * h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const f16x8*>(qg + (off + 32 * s));
+  };
+
+  int item = blockIdx.x, buf = 0;
+  if (item < items) {
+    dma_kv(item, 0);
+    load_q(item, qf);
+  }
+  while (item < items) {
+    // this item's images and Q fragments have landed (issued an item ago).  (A counted wait that leaves the previous
+    // item's row stores in flight is of no use here: the stores sit under per-lane predicates, so the compiler's own
+    // wait for the Q registers below counts none of them and drains everything anyway.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+    __syncthreads();   // ... and every wave is done with the other buffer (the previous item's)
+    const int next = item + gridDim.x;
+    if (next < items) {
+      dma_kv(next, buf ^ 1);
+      load_q(next, qn);
+    }
+    if (active) {
+      int opaque = 0;
+      asm volatile("" : "+v"(opaque));
+      const char* ksl = lds + buf * 2 * kF2Img + opaque;
+      const char* vsl = ksl + kF2Img;
+      const int head = item % a.h;
+      const int64_t b = item / a.h;
+      // ---- S^T = K . Q^T ----
+      f32x16 sc[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+        const int key = kt * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int c = 2 * s + h;
+          const f16x8 kf = *reinterpret_cast<const f16x8*>(ksl + key * 128 + ((c ^ ((key >> 1) & 7)) << 4));
+          sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sc[kt], 0, 0, 0);
+        }
+      }
+      // ---- softmax over keys; only the last key tile can hold keys >= T
+      float mx = ninf;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = (NKT - 1) * 32 + acc_row(i, h);
+        sc[NKT - 1][i] = key < a.t ? sc[NKT - 1][i] : ninf;
+      }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mxs = mx * a.scale_log2e;
+      float sum = 0.f;
+#define HCIR_EXP_TILE2(KT)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                    \
+    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[KT][i], a.scale_log2e, -mxs));           \
+    sc[KT][i] = p;                                                                                    \
+    sum += p;                                                                                         \
+  }
+      f32x16 oacc[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[t2][i] = 0.f;
+      HCIR_EXP_TILE2(0)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        f16x8 pf[2], vf[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[s][j] = (_Float16)sc[kt][8 * s + j];
+#pragma unroll
+          for (int hdt = 0; hdt < 2; ++hdt) {
+            const int c0 = 32 * hdt + 16 * (grp & 1) + 4 * (li & 3);
+            const int kb = 32 * kt + 16 * s + 4 * (grp >> 1) + (li >> 2);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int key = kb + 8 * half;
+              const int col = c0 ^ (((key >> 1) & 1) << 5);
+              const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                  (fp16x4_t __attribute__((address_space(3)))*)(vsl + key * 128 + col * 2));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vf[s][hdt][4 * half + e] = (_Float16)v4[e];
+            }
+          }
+        }
+        if (kt + 1 < NKT) {
+          HCIR_EXP_TILE2(kt + 1)
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int hdt = 0; hdt < 2; ++hdt)
+            oacc[hdt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s][hdt], pf[s], oacc[hdt], 0, 0, 0);
+      }
+#undef HCIR_EXP_TILE2
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      // ---- whole 128-B rows through the wave's 4 KB transposition tile, then the lse
+      char* ot = lds + 4 * kF2Img + wave * 4096 + opaque;
+#pragma unroll
+      for (int hdt = 0; hdt < 2; ++hdt) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)(oacc[hdt][4 * g4 + e] * inv);
+          const int chunk = 4 * hdt + g4;
+          *reinterpret_cast<f16x4*>(ot + r * 128 + ((chunk ^ (r & 7)) << 4) + 8 * h) = o;
+        }
+      }
+      const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * 128 + ((cc ^ (row & 7)) << 4));
+        const int q = q0 + row;
+        if (q < a.nq)
+          *reinterpret_cast<u32x4*>(a.out + (b * a.nq + q) * ((int64_t)a.h * 64) + head * 64 + cc * 8) = v;
+      }
+      if (a.lse && h == 0 && q0 + r < a.nq)
+        a.lse[(b * a.h + head) * (int64_t)a.t + q0 + r] = mxs + __builtin_amdgcn_logf(sum);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    item = next;
+    buf ^= 1;
   }
 }
 
@@ -414,6 +599,14 @@ static int attn_fwd_launch(const void* qkv, int64_t b, int32_t t, int32_t h, int
     HCIR_LAUNCH_CHECK();
     return HCIR_OK;
   }
+#ifndef HCIR_ATTN_FWD_V1   // build flag: the 4-wave kernel at every T (A/B runs)
+  if (nqt == kF2NKT && nq == t && b * h >= 512) {
+    const int items = (int)(b * h);
+    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(256), dim3(64 * kF2NKT), 0, st, a, items);
+    HCIR_LAUNCH_CHECK();
+    return HCIR_OK;
+  }
+#endif
 #define LAUNCH(N) hipLaunchKernelGGL(attn_fwd_kernel<N>, grid, dim3(256), 0, st, a)
   // the kernel is built for NKT key tiles; 4 waves walk the query tiles
   switch (nqt) {

@@ -29,7 +29,7 @@ def short(name):
     m = re.search(r"(gemm_f16_big_kernel<\d+)", name)
     if m:
         return m.group(1) + ">"
-    m = re.search(r"(attn_fwd_kernel<\d+>|layernorm_f16_kernel|sim_topk_scan|topk_merge_kernel|patch_embed_kernel|"
+    m = re.search(r"(attn_fwd2_kernel|attn_fwd_kernel<\d+>|layernorm_f16_kernel|sim_topk_scan|topk_merge_kernel|patch_embed_kernel|"
                   r"ln_stats_finalize_kernel|topk_refine_kernel|gemm_f16_kernel<\d+)", name)
     if m:
         return m.group(1)

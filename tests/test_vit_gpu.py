@@ -289,6 +289,28 @@ def test_attention(L, b, t, h):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), atol=6e-3, rtol=0)
 
 
+def test_attention_persistent_kernel_matches_per_item_kernel(L):
+    """>= 512 (b, head) items at 193..224 tokens take the persistent double-buffered kernel (seven waves, the next
+    item's K / V images in flight under the current item's compute); fewer items take the workgroup-per-item kernel.
+    Same arithmetic: the outputs of one 48-image call equal those of two 24-image calls bit for bit, run after run."""
+    b, t, h = 48, 197, 12
+    g = torch.Generator().manual_seed(77)
+    qkv = (torch.randn(b, t, 3 * h * 64, generator=g) * 0.7).half().cuda()
+    scale = 64 ** -0.5
+    whole = torch.empty(b, t, h * 64, dtype=torch.float16, device="cuda")
+    halves = torch.empty_like(whole)
+    for lo in (0, b // 2):
+        assert L.hcir_attn_fwd(qkv[lo:lo + b // 2].data_ptr(), b // 2, t, h, 64, scale, t, halves[lo:lo + b // 2].data_ptr(),
+                               _st()) == 0
+    for rep in range(5):
+        whole.fill_(float("nan"))
+        assert L.hcir_attn_fwd(qkv.data_ptr(), b, t, h, 64, scale, t, whole.data_ptr(), _st()) == 0
+        assert torch.equal(whole, halves), rep
+    q, k, v = qkv.float().reshape(b, t, 3, h, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q * scale) @ k.transpose(-2, -1), dim=-1) @ v).transpose(1, 2).reshape(b, t, h * 64)
+    assert (whole.float() - ref).abs().max().item() <= 4e-3
+
+
 @pytest.mark.parametrize("b,t,h,hd", [(2, 257, 16, 80), (1, 197, 3, 128), (3, 33, 2, 32), (1, 288, 2, 96), (2, 50, 4, 48)])
 def test_attention_other_head_dims(L, b, t, h, hd):
     """head_dim != 64 (vit_huge_patch14: 1280 / 16 = 80, HP/src/models_vit.py:266-270): the generic kernel."""

@@ -66,3 +66,12 @@ __device__ __forceinline__ void lds_dma16(const void* src_base, uint32_t src_off
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(src_off), "s"(src_base), "s"(m)
                : "memory");
 }
+// Same, per-lane 64-bit source address (no wave-uniform base at hand).
+__device__ __forceinline__ void lds_dma16_v(const void* gsrc, uint32_t lds_wave_addr) {
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_v_nt(const void* gsrc, uint32_t lds_wave_addr) {   // non-temporal
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(m) : "memory");
+}

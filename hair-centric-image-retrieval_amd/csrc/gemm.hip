@@ -692,12 +692,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     // pieces 0..3 are W rows, 4..7 activation rows (i is a constant after unrolling).  Default cache policy
     // on both operands: `nt` (aux 2) on the activation rows measured +-1 %, on the W rows -9..-13 %
     // (every CU of an XCD re-reads them from L2)
+#ifndef HCIR_GEMM_BUILTIN_DMA   // the transfer issued outside the compiler's view (common.h lds_dma16): +1.3 % over
+                                // the layer against the builtin (qkv +2.6 %), which stays behind this flag for A/B runs
+    lds_dma16((i < 4 ? wbase : abase) + issue_kc * 128, soff[i],
+              lds_addr(lds) + slot * G256::STAGE_BYTES + ((tid & ~63) + G256::NT * i) * 16);
+#else
     const char* sp = (i < 4 ? wbase : abase) + issue_kc * 128 + soff[i];
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)sp,
         (__attribute__((address_space(3))) void*)(lds + slot * G256::STAGE_BYTES +
                                                    ((tid & ~63) + G256::NT * i) * 16),
         16, 0, 0);
+#endif
   };
   auto issue_advance = [&]() {
     if (++issue_kc == nkc) {
@@ -1094,11 +1100,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_mid_kernel(GemmArgs g, int ti
   };
   int issue_ti = 0, issue_kc = 0;
   auto issue_piece = [&](int slot, int i) {  // i constant after unrolling: pieces 0..3 W rows, 4..9 activation rows
+#ifndef HCIR_GEMM_BUILTIN_DMA
+    lds_dma16((i < GMid::NW ? wbase : abase) + issue_kc * 128, soff[i],
+              lds_addr(lds) + slot * GMid::STAGE_BYTES + ((tid & ~63) + GMid::NT * i) * 16);
+#else
     const char* sp = (i < GMid::NW ? wbase : abase) + issue_kc * 128 + soff[i];
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)sp,
         (__attribute__((address_space(3))) void*)(lds + slot * GMid::STAGE_BYTES + ((tid & ~63) + GMid::NT * i) * 16),
         16, 0, 0);
+#endif
   };
   auto issue_advance = [&]() {
     if (++issue_kc == nkc) {

@@ -132,6 +132,14 @@ __device__ __forceinline__ void sim_stage_glds(char* stage, const T* __restrict_
       qr = qr > q_last ? q_last : qr;
       src = q + qr * (int64_t)d + k0;
     }
+#ifndef HCIR_SIM_BUILTIN_DMA   // the transfer outside the compiler's view (common.h); the callers retire it
+                          // with sim_glds_retire_and_sync().  (No cache-policy bit on this path.)
+    if (AUX_STREAM != 0 && ((Cfg::NT * i) / 8 + 63 / 8 < Cfg::GM || row < Cfg::GM))
+      lds_dma16_v_nt(src, lds_addr(stage) + (wave_base + Cfg::NT * i) * 16);
+    else
+      lds_dma16_v(src, lds_addr(stage) + (wave_base + Cfg::NT * i) * 16);
+    continue;
+#endif
     // rows of one instruction are all stream rows or all resident rows (GM is a multiple of 8)
     if ((Cfg::NT * i) / 8 + 63 / 8 < Cfg::GM || row < Cfg::GM)
       __builtin_amdgcn_global_load_lds(

@@ -104,6 +104,11 @@ SIGNATURES = {
     "hcir_jpeg_stage_batch": (c_int, [c_vp, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp, c_i32]),
     "hcir_jpeg_workspace_bytes": (c_sz, [c_vp, c_i64, c_i32, c_i32]),
     "hcir_jpeg_decode_window_u8": (c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_png_stage_bytes": (c_sz, [c_vp, c_sz]),
+    "hcir_png_stage": (c_int, [c_vp, c_sz, c_i32, c_vp, c_vp, c_sz, c_sz, c_vp]),
+    "hcir_png_stage_batch": (c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_vp, c_vp, c_i32]),
+    "hcir_png_workspace_bytes": (c_sz, [c_vp, c_i64, c_i32, c_i32]),
+    "hcir_png_decode_window_u8": (c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
 }
 
 

@@ -523,6 +523,64 @@ int hcir_jpeg_decode_window_u8(const void* blob_dev, const hcir_jpeg_header* hdr
                                int32_t win_w, uint8_t* out, int32_t* status_dev, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * PNG decode on the device: the format of every hair-region crop the reference lists —
+ *   HairPretraining/data/data_train.csv:2-3 ("133101_hair.png", ...: 103 945 of 103 945 rows),
+ *   HairPretraining/data/data_{train,test}_combination3.csv, the four PNGs of assets/hair_region_only.
+ * Replaces, as the JPEG entry points above do,
+ *   read_file + torchvision.io.decode_image(img_bytes, mode=RGB)      HP/utils/dataloader.py:28-31
+ *   PIL.Image.open(path).convert('RGB')                               src/models/hair_encoder.py:108,169
+ * in front of knn_transform's CenterCrop (HP/utils/transform.py:11).  Output bytes equal libpng's / Pillow's:
+ * inflate and the scanline filters are exact integer algorithms (RFC 1950/1951, PNG spec §9).
+ *
+ * Scope: 8-bit samples, non-interlaced, colour types 0 (grey), 2 (RGB), 3 (palette), 4 (grey + alpha),
+ * 6 (RGBA); the RGB conversion is the one `convert('RGB')` / `mode=RGB` make: grey replicated, alpha dropped,
+ * palette indices through PLTE.  Everything else (16-bit, 1/2/4-bit, Adam7) is HCIR_ERR_UNSUPPORTED from
+ * hcir_png_stage and the loader keeps its host decoder for that file.
+ *
+ * Two steps, as for JPEG.  (1) HOST: hcir_png_stage walks the chunks (IHDR, PLTE, IDAT ..., optionally verifying
+ * every chunk's CRC-32 as Pillow does), fills a header and concatenates the IDAT payloads — the zlib stream —
+ * into the caller's (pinned) staging blob:
+ *     [ hcir_png_header x b ][ image 0: zlib stream, zero padded to 16 B + 16 B ][ image 1 ... ]
+ * (2) DEVICE: hcir_png_decode_window_u8 runs one wavefront per image that inflates the stream up to the last
+ * scanline the window needs (stored, fixed and dynamic Huffman blocks; the 32 KB history is an LDS ring; match
+ * copies are lane-parallel), then one wavefront per image that undoes the filters of rows 0..last along the
+ * anti-diagonals of (row, pixel) — lane = row, so Paeth's left / up / upper-left are a register and two
+ * neighbour-lane reads — and writes the window's RGB8 pixels.
+ * ------------------------------------------------------------------ */
+typedef struct hcir_png_header {
+  int32_t width, height;
+  int32_t color_type;    /* 0, 2, 3, 4, 6                                                */
+  int32_t bpp;           /* bytes per pixel of the filtered scanlines: 1, 3, 1, 2, 4      */
+  uint32_t stream_bytes; /* bytes of the zlib stream (IDAT payloads concatenated)         */
+  uint32_t reserved;
+  uint64_t stage_offset; /* byte offset of the stream inside the staging blob (16-aligned) */
+  uint8_t palette[768];  /* PLTE, RGB triples (colour type 3)                             */
+} hcir_png_header;
+
+#define HCIR_PNG_VERIFY_CRC 1 /* flags: verify the CRC-32 of every chunk while staging (Pillow's default)   */
+
+/* HOST.  Bytes of staging blob needed for this file's stream (0 if it is not a PNG of the subset above). */
+size_t hcir_png_stage_bytes(const uint8_t* file, size_t nbytes);
+/* HOST.  Parse `file`, fill *hdr, copy the zlib stream to blob + blob_offset (multiple of 16); *used = bytes
+ * written (multiple of 16).  HCIR_ERR_UNSUPPORTED / HCIR_ERR_INVALID (not a PNG, corrupt chunk structure or CRC) /
+ * HCIR_ERR_WORKSPACE. */
+int hcir_png_stage(const uint8_t* file, size_t nbytes, int32_t flags, hcir_png_header* hdr, uint8_t* blob,
+                   size_t blob_offset, size_t blob_cap, size_t* used);
+/* HOST.  The same for b files into one blob (headers first), `nthreads` worker threads; status[i] per file, a
+ * rejected file gets a zeroed header (width 0) that the device skips.  blob == NULL: only *blob_used and status[]. */
+int hcir_png_stage_batch(const uint8_t* const* files, const size_t* nbytes, int64_t b, int32_t flags, uint8_t* blob,
+                         size_t blob_cap, size_t* blob_used, int32_t* status, int32_t nthreads);
+/* HOST.  Workspace bytes for a batch: the inflated scanlines 0..last needed row of every image. */
+size_t hcir_png_workspace_bytes(const hcir_png_header* hdrs_host, int64_t b, int32_t win_h, int32_t win_w);
+/* blob_dev: DEVICE copy of the staging blob; hdrs_host: the same headers on the host (sizing only).
+ * out [b][win_h][win_w][3] uint8 = the CenterCrop((win_h, win_w)) window of every decoded image, zero where the
+ * window leaves the image.  status_dev [b] int32 (may be NULL): 0, or HCIR_ERR_INVALID when the stream is corrupt
+ * (bad block type / code set / distance, a filter type > 4, or it ends before the last needed scanline). */
+int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_header* hdrs_host, int64_t b, int32_t win_h,
+                              int32_t win_w, uint8_t* out, int32_t* status_dev, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

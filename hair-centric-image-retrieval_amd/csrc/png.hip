@@ -31,11 +31,21 @@
 
 namespace {
 
-constexpr int kRing = 32768;  // deflate's maximum distance: the ring never needs to be larger (reads of a copy come
-                              // before its writes, pending literals are written in stream order)
+constexpr int kRing = 32768;  // deflate's maximum distance: the ring never needs to be larger (the reads of a copy
+                              // come before its writes; literals that could alias a far source are written in order)
 constexpr int kLitRoot = 10, kDistRoot = 9, kClRoot = 7;
 constexpr uint32_t K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_DIST = 4, K_LONG = 5, K_CL = 6;
 enum { T_CL = 0, T_LIT = 1, T_DIST = 2 };
+// A decoded symbol, packed: bits 0-6 the walk's step = stream bits it takes (code + extra bits; a match: length AND
+// distance codes), or 64 for an entry the walk must stop on; bits 7-8 kind; literal: bits 9-16 the byte; match:
+// bits 9-16 length - 3, bits 17-31 distance - 1.
+constexpr uint32_t S_LIT = 0, S_MATCH = 1, S_EOB = 2, S_SLOW = 3;  // S_SLOW: left to the serial decoder
+constexpr uint32_t kStop = 64;
+__device__ __forceinline__ uint32_t pack_lit(uint32_t step, uint32_t byte) { return step | (S_LIT << 7) | (byte << 9); }
+__device__ __forceinline__ uint32_t pack_match(uint32_t step, uint32_t len, uint32_t dist) {
+  return step | (S_MATCH << 7) | ((len - 3) << 9) | ((dist - 1) << 17);
+}
+constexpr int kSpan = 4;                                           // 64-bit windows looked up per pass (256 positions)
 
 struct PngBatch {
   const uint8_t* blob;
@@ -45,7 +55,54 @@ struct PngBatch {
   int32_t* status;
   uint8_t* raw;
   uint64_t raw_stride;
+  uint64_t* diag;  // -DHCIR_PNG_STAMPS: 16 counters per image (tools/diag_png.py)
 };
+
+#ifdef HCIR_PNG_STAMPS
+#define STAMP_DECL uint64_t st_t0 = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_n[4] = {0, 0, 0, 0}
+#define STAMP(i)                                         \
+  do {                                                   \
+    const uint64_t st_now = __builtin_readcyclecounter(); \
+    st_acc[i] += st_now - st_t0;                         \
+    st_t0 = st_now;                                      \
+  } while (0)
+#define COUNT(i, v) st_n[i] += (v)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define COUNT(i, v)
+#endif
+
+// One wave per workgroup: LDS operations of a wave complete in order, so lanes see each other's LDS writes without
+// a barrier instruction; what is needed is that the compiler keeps the order (no s_waitcnt vmcnt(0) as __syncthreads
+// would put in front of its s_barrier: the ring's write-out stores to HBM need not have landed).
+#define WAVE_SYNC()                                           \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+struct Canon {  // canonical code ranges by length
+  uint32_t first[16], count[16], offs[16];
+};
+
+struct Smem {
+  uint8_t ring[kRing];
+  uint32_t lit_tab[1 << kLitRoot];
+  uint32_t dist_tab[1 << kDistRoot];  // also the code-length code's table while a block header is read
+  Canon lit_cn, dist_cn;
+  uint16_t lit_sorted[288], dist_sorted[32];
+  uint8_t lens[320 + 12];
+  uint8_t cl_lens[20];
+  uint32_t symq[128 + 1];         // decoded symbols waiting for their batch of 64 (a ring) + a dump slot
+  uint8_t dump[64];               // where the lanes beyond a copy's length write
+  uint32_t u_bp, u_last, u_type;  // wave-uniform state handed between block_header() and the kernel
+  int32_t u_err;
+};
+typedef __attribute__((address_space(3))) Smem Smem3;
+
+__device__ __forceinline__ uint32_t U(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ uint32_t entry(uint32_t len, uint32_t kind, uint32_t extra, uint32_t val) {
   return len | (kind << 4) | (extra << 8) | (val << 16);
@@ -71,22 +128,21 @@ __device__ __forceinline__ uint32_t symbol_entry(uint32_t sym, uint32_t len) {
   return entry(len, K_DIST, eb, 1 + ((2 + (sym & 1)) << eb));
 }
 
-struct Canon {  // per table, in LDS: canonical code ranges by length
-  uint32_t first[16], count[16], offs[16];
-};
-
 // Build one decode table from code lengths lens[0..n) (LDS).  Returns 0, or 1 when the set of lengths is not
 // acceptable to zlib's inflate_table: over-subscribed, or incomplete with anything but a single 1-bit code
 // (a code-length code must be complete).  ROOT-bit table `tab`, symbols sorted by (length, value) in `sorted`.
 template <int ROOT, int TYPE, int MAXN>
-__device__ int build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* sorted, Canon* cn, int lane) {
+__device__ __forceinline__ int build_table(const __attribute__((address_space(3))) uint8_t* lens, int n,
+                                           __attribute__((address_space(3))) uint32_t* tab,
+                                           __attribute__((address_space(3))) uint16_t* sorted,
+                                           __attribute__((address_space(3))) Canon* cn, int lane) {
   constexpr int kChunks = (MAXN + 63) / 64;
   uint32_t run[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) run[l] = 0;
   uint32_t myrank[kChunks], mylen[kChunks];
 #pragma unroll
-  for (int c = 0; c < kChunks; ++c) {
+  for (int c = 0; c < kChunks; ++c) {  // rank every symbol inside its length class: ballots, no serial pass
     const int s = c * 64 + lane;
     const uint32_t l = s < n ? lens[s] : 0;
     mylen[c] = l;
@@ -137,7 +193,7 @@ __device__ int build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* 
     uint32_t v = entry(0, maxlen > ROOT ? K_LONG : K_INVALID, 0, 0);
     const uint32_t rev = __brev((uint32_t)e);
 #pragma unroll
-    for (int L = (ROOT < 15 ? ROOT : 15); L >= 1; --L) {  // descending, so that the shortest match is kept
+    for (int L = (ROOT < 15 ? ROOT : 15); L >= 1; --L) {
       const uint32_t c = rev >> (32 - L), idx = c - first[L];
       if (c >= first[L] && idx < run[L]) v = symbol_entry<TYPE>(sorted[offs[L] + idx], (uint32_t)L);
     }
@@ -147,18 +203,21 @@ __device__ int build_table(const uint8_t* lens, int n, uint32_t* tab, uint16_t* 
   return 0;
 }
 
-// A code longer than the table's root: canonical range search over lengths ROOT+1..15 (uniform).
+// A code longer than the table's root: canonical range test, lane L tests length L (ROOT < L < 16).  Uniform result.
 template <int ROOT, int TYPE>
-__device__ __noinline__ uint32_t long_code(uint32_t bits, const uint16_t* sorted, const Canon* cn) {
-  const uint32_t rev = __brev(bits);
-  for (int L = ROOT + 1; L < 16; ++L) {
-    const uint32_t c = rev >> (32 - L), f = cn->first[L], idx = c - f;
-    if (c >= f && idx < cn->count[L]) return symbol_entry<TYPE>(sorted[cn->offs[L] + idx], (uint32_t)L);
-  }
-  return entry(0, K_INVALID, 0, 0);
+__device__ __forceinline__ uint32_t long_code(uint32_t bits, const __attribute__((address_space(3))) uint16_t* sorted,
+                                              const __attribute__((address_space(3))) Canon* cn, int lane) {
+  const int L = (lane & 15) > ROOT ? (lane & 15) : ROOT + 1;
+  const uint32_t f = cn->first[L], cnt = cn->count[L], of = cn->offs[L];
+  const uint32_t c = __brev(bits) >> (32 - L), idx = c - f;
+  const uint64_t hit = __ballot(lane < 16 && (lane & 15) > ROOT && c >= f && idx < cnt);
+  if (!hit) return entry(0, K_INVALID, 0, 0);
+  const int hl = __builtin_ctzll(hit);
+  const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)(of + idx), hl);
+  return U(symbol_entry<TYPE>(sorted[si], (uint32_t)hl));
 }
 
-struct Words {  // the compressed stream, 128 words at a time in two VGPRs
+struct Words {  // the compressed stream, 128 words at a time in two VGPRs (lane i: words base+i, base+64+i)
   const uint32_t* w;
   uint32_t nwords, base;
   uint32_t v0, v1;
@@ -172,59 +231,375 @@ struct Words {  // the compressed stream, 128 words at a time in two VGPRs
     v0 = fetch(base);
     v1 = fetch(base + 64);
   }
-  __device__ __forceinline__ uint32_t word(uint32_t k) const {  // k uniform, < 128; v1 (the prefetch) only if needed
-    if (k < 64) return __builtin_amdgcn_readlane(v0, k);
-    return __builtin_amdgcn_readlane(v1, k - 64);
-  }
-  // the 64 stream bits from bit position bp on (bp uniform)
-  __device__ __forceinline__ uint64_t peek(uint32_t bp) {
-    uint32_t k = (bp >> 5) - base;
-    if (k >= 64) {  // the look may touch words k .. k+2: keep them inside [base, base+128)
+  // make words [first, first + 11) readable; returns first - base (< 64)
+  __device__ __forceinline__ uint32_t cover(uint32_t first) {
+    uint32_t k = first - base;
+    if (k >= 64) {
       if (k < 128) {
         v0 = v1;
         base += 64;
-        v1 = fetch(base + 64);
+        v1 = fetch(base + 64);  // needed 53+ words from now: its latency is not waited for here
       } else {
-        seek(bp >> 5);
+        seek(first);
       }
-      k = (bp >> 5) - base;
+      k = first - base;
     }
-    uint32_t w0, w1, w2;
-    if (k < 62) {
-      w0 = __builtin_amdgcn_readlane(v0, k), w1 = __builtin_amdgcn_readlane(v0, k + 1),
-      w2 = __builtin_amdgcn_readlane(v0, k + 2);
-    } else {
-      w0 = word(k), w1 = word(k + 1), w2 = word(k + 2);
-    }
-    const uint32_t sh = bp & 31;
+    return k;
+  }
+  __device__ __forceinline__ uint32_t word(uint32_t k) const {  // k uniform, < 128
+    if (k < 64) return (uint32_t)__builtin_amdgcn_readlane((int)v0, (int)k);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v1, (int)(k - 64));
+  }
+  // the 64 stream bits from bit position bp on (uniform)
+  __device__ __forceinline__ uint64_t peek(uint32_t bp) {
+    const uint32_t k = cover(bp >> 5);
+    const uint32_t w0 = word(k), w1 = word(k + 1), w2 = word(k + 2), sh = bp & 31;
     const uint64_t lo = ((uint64_t)w1 << 32) | w0;
     return sh ? (lo >> sh) | ((uint64_t)w2 << (64 - sh)) : lo;
   }
 };
 
-__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, int lane, uint32_t* total) {
-  uint32_t s = v;
+// ---- one block header: type, and for Huffman blocks the code tables (RFC 1951 3.2.3 - 3.2.7).  Kept out of line:
+// its uniform arrays live in scalar registers and would otherwise crowd the decode loop's.  State goes through LDS.
+__device__ __noinline__ void block_header(const uint32_t* words, uint32_t nwords, uint32_t total_bits, Smem3* sm,
+                                          int lane) {
+  nwords = U(nwords);
+  total_bits = U(total_bits);
+  Words in;
+  in.w = reinterpret_cast<const uint32_t*>(
+      ((uint64_t)U((uint32_t)((uint64_t)words >> 32)) << 32) | U((uint32_t)(uint64_t)words));
+  in.nwords = nwords;
+  in.lane = lane;
+  uint32_t bp = U(sm->u_bp);
+  in.seek(bp >> 5);
+  int err = 0;
+  uint32_t last = 0, type = 0;
+  do {
+    if (bp + 3 > total_bits) {
+      err = 1;
+      break;
+    }
+    uint64_t win = in.peek(bp);
+    last = (uint32_t)win & 1;
+    type = (uint32_t)(win >> 1) & 3;
+    bp += 3;
+    if (type == 3) {
+      err = 1;
+      break;
+    }
+    if (type == 0) break;  // stored: the kernel copies the bytes
+    if (type == 1) {
+      for (int s = lane; s < 288; s += 64) sm->lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+      __syncthreads();
+      build_table<kLitRoot, T_LIT, 288>(sm->lens, 288, sm->lit_tab, sm->lit_sorted, &sm->lit_cn, lane);
+      if (lane < 32) sm->lens[lane] = 5;  // 30 and 31 are part of the fixed code and never valid (symbol_entry)
+      __syncthreads();
+      build_table<kDistRoot, T_DIST, 32>(sm->lens, 32, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane);
+      break;
+    }
+    if (bp + 14 > total_bits) {
+      err = 1;
+      break;
+    }
+    win = in.peek(bp);
+    const uint32_t hlit = ((uint32_t)win & 31) + 257, hdist = ((uint32_t)(win >> 5) & 31) + 1,
+                   hclen = ((uint32_t)(win >> 10) & 15) + 4;
+    bp += 14;
+    if (hlit > 286 || hdist > 30) {  // zlib: "too many length or distance symbols"
+      err = 1;
+      break;
+    }
+    win = in.peek(bp);  // up to 19 x 3 = 57 bits
+    if (lane < 19) {
+      // order of the code-length code lengths (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+      constexpr uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      uint32_t pos = 0;  // which transmitted slot carries symbol `lane`
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(s, o);
-    if (lane >= o) s += t;
+      for (int i = 0; i < 19; ++i)
+        if (kOrder[i] == lane) pos = (uint32_t)i;
+      sm->cl_lens[lane] = pos < hclen ? (uint8_t)((win >> (3 * pos)) & 7) : 0;
+    }
+    bp += 3 * hclen;
+    __syncthreads();
+    if (build_table<kClRoot, T_CL, 19>(sm->cl_lens, 19, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane)) {
+      err = 1;
+      break;
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0;
+    while (i < total) {
+      if (bp > total_bits) {
+        err = 1;
+        break;
+      }
+      win = in.peek(bp);
+      const uint32_t e = U(sm->dist_tab[(uint32_t)win & ((1 << kClRoot) - 1)]);
+      if (((e >> 4) & 7) != K_CL) {
+        err = 1;
+        break;
+      }
+      const uint32_t n = e & 15, sym = e >> 16;
+      uint32_t rep = 1, val = sym;
+      bp += n;
+      if (sym == 16) {
+        if (i == 0) {
+          err = 1;
+          break;
+        }
+        rep = 3 + ((uint32_t)(win >> n) & 3);
+        val = prev;
+        bp += 2;
+      } else if (sym == 17) {
+        rep = 3 + ((uint32_t)(win >> n) & 7);
+        val = 0;
+        bp += 3;
+      } else if (sym == 18) {
+        rep = 11 + ((uint32_t)(win >> n) & 127);
+        val = 0;
+        bp += 7;
+      }
+      if (i + rep > total) {
+        err = 1;
+        break;
+      }
+      for (uint32_t j = (uint32_t)lane; j < rep; j += 64) sm->lens[i + j] = (uint8_t)val;
+      i += rep;
+      prev = val;
+    }
+    if (err) break;
+    __syncthreads();
+    if (U(sm->lens[256]) == 0) {  // zlib: "invalid code -- missing end-of-block"
+      err = 1;
+      break;
+    }
+    if (build_table<kLitRoot, T_LIT, 288>(sm->lens, (int)hlit, sm->lit_tab, sm->lit_sorted, &sm->lit_cn, lane)) {
+      err = 1;
+      break;
+    }
+    // the distance lengths follow the literal/length ones; move them to the front for the builder
+    uint8_t dl = 0;
+    if (lane < 32) dl = (uint32_t)lane < hdist ? sm->lens[hlit + lane] : 0;
+    __syncthreads();
+    if (lane < 32) sm->lens[lane] = dl;
+    __syncthreads();
+    if (build_table<kDistRoot, T_DIST, 32>(sm->lens, (int)hdist, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane)) err = 1;
+  } while (false);
+  __syncthreads();
+  if (lane == 0) {
+    sm->u_bp = bp;
+    sm->u_err = err;
+    sm->u_last = last;
+    sm->u_type = type;
   }
-  *total = __shfl(s, 63);
+  __syncthreads();
+}
+
+// ---- lane-parallel lookup: the symbol that WOULD start at this lane's bit position (lo/hi = the 64 stream bits
+// from there), literal/length code, extra bits, distance code and extra bits, all resolved from the two tables.
+// Three stages over kSpan windows, so that the windows' table reads are in flight together.
+__device__ __forceinline__ void lookup_span(const Smem3* sm, const uint32_t* lo, const uint32_t* hi, uint32_t* out) {
+  uint32_t e1[kSpan], e2[kSpan], d32[kSpan], len[kSpan];
+#pragma unroll
+  for (int r = 0; r < kSpan; ++r) e1[r] = sm->lit_tab[lo[r] & ((1 << kLitRoot) - 1)];
+#pragma unroll
+  for (int r = 0; r < kSpan; ++r) {
+    const uint32_t n1 = e1[r] & 15, eb = (e1[r] >> 8) & 15;
+    const uint64_t w1 = (((uint64_t)hi[r] << 32) | lo[r]) >> n1;
+    len[r] = (e1[r] >> 16) + ((uint32_t)w1 & ((1u << eb) - 1));
+    d32[r] = (uint32_t)(w1 >> eb);  // >= 44 valid bits were left: a distance takes at most 28
+    e2[r] = sm->dist_tab[d32[r] & ((1 << kDistRoot) - 1)];
+  }
+#pragma unroll
+  for (int r = 0; r < kSpan; ++r) {
+    const uint32_t k1 = (e1[r] >> 4) & 7, n1 = e1[r] & 15, eb = (e1[r] >> 8) & 15;
+    const uint32_t k2 = (e2[r] >> 4) & 7, dn = e2[r] & 15, deb = (e2[r] >> 8) & 15;
+    const uint32_t dist = (e2[r] >> 16) + ((d32[r] >> dn) & ((1u << deb) - 1));
+    // a long or invalid code: the walk stops there and it is decoded serially
+    uint32_t res = kStop | (S_SLOW << 7);
+    if (k1 == K_LIT) res = pack_lit(n1, e1[r] >> 16);
+    if (k1 == K_EOB) res = kStop | (S_EOB << 7) | (n1 << 9);
+    if (k1 == K_LEN && k2 == K_DIST) res = pack_match(n1 + eb + dn + deb, len[r], dist);
+    out[r] = res;
+  }
+}
+
+// the same for ONE position, serially, with the long codes searched (wave-uniform).  The packed symbol; for the
+// end of the block kStop | S_EOB | its code length << 9; ~0: no valid symbol starts here.
+__device__ __noinline__ uint32_t lookup_slow(uint32_t lo, uint32_t hi, Smem3* sm, int lane) {
+  lo = U(lo);
+  hi = U(hi);
+  uint32_t e1 = U(sm->lit_tab[lo & ((1 << kLitRoot) - 1)]);
+  if (((e1 >> 4) & 7) == K_LONG) e1 = long_code<kLitRoot, T_LIT>(lo, sm->lit_sorted, &sm->lit_cn, lane);
+  const uint32_t k1 = (e1 >> 4) & 7, n1 = e1 & 15;
+  if (k1 == K_LIT) return pack_lit(n1, e1 >> 16);
+  if (k1 == K_EOB) return kStop | (S_EOB << 7) | (n1 << 9);
+  if (k1 != K_LEN) return ~0u;
+  const uint32_t eb = (e1 >> 8) & 15;
+  const uint64_t w1 = (((uint64_t)hi << 32) | lo) >> n1;
+  const uint32_t len = (e1 >> 16) + ((uint32_t)w1 & ((1u << eb) - 1));
+  const uint32_t d32 = (uint32_t)(w1 >> eb);
+  uint32_t e2 = U(sm->dist_tab[d32 & ((1 << kDistRoot) - 1)]);
+  if (((e2 >> 4) & 7) == K_LONG) e2 = long_code<kDistRoot, T_DIST>(d32, sm->dist_sorted, &sm->dist_cn, lane);
+  if (((e2 >> 4) & 7) != K_DIST) return ~0u;
+  const uint32_t dn = e2 & 15, deb = (e2 >> 8) & 15;
+  const uint32_t dist = (e2 >> 16) + ((d32 >> dn) & ((1u << deb) - 1));
+  return pack_match(n1 + eb + dn + deb, len, dist);
+}
+
+// ---- the serial part: the walk from symbol start to symbol start over the four windows of a pass.
+// c0..c3: the windows (lane = bit position, value = packed symbol).  In: w, p = window and position (< 64) to start
+// at.  Each start's bit is set in its window's mask.  Out: w = 4 and p = the start position inside the next pass, or
+// w < 4: the walk landed on a stop entry e (step 64) at position p of window w (its bit is not set).
+// Written out: six scalar instructions per symbol and one conditional branch.  Measured on gfx950
+// (tools/ubench/walk_latency.hip): v_readlane -> SALU -> v_readlane round trip 29 cycles, a dependent SALU
+// instruction 4, a conditional branch 16 NOT taken and 20 taken - the branch count is what this loop is built around.
+#define HCIR_WALK_STEP(C, M, X)          \
+  "v_readlane_b32 %[e], %[" C "], %[p]\n\t" \
+  "s_bitset1_b64 %[" M "], %[p]\n\t"        \
+  "s_and_b32 %[t], %[e], 127\n\t"           \
+  "s_add_u32 %[p], %[p], %[t]\n\t"          \
+  "s_cmp_gt_u32 %[p], 63\n\t"               \
+  "s_cbranch_scc1 " X "_%=\n\t"
+#define HCIR_WALK_WINDOW(N, C, M, NEXT)                                                                    \
+  ".Lw" N "_%=:\n\t" HCIR_WALK_STEP(C, M, ".Lx" N) HCIR_WALK_STEP(C, M, ".Lx" N) HCIR_WALK_STEP(C, M, ".Lx" N) \
+      HCIR_WALK_STEP(C, M, ".Lx" N) "s_branch .Lw" N "_%=\n"                                               \
+  ".Lx" N "_%=:\n\t"                                                                                       \
+  "s_sub_u32 %[p], %[p], 64\n\t"                                                                           \
+  "s_bitcmp1_b32 %[e], 6\n\t"                                                                              \
+  "s_cbranch_scc0 " NEXT "_%=\n\t"                                                                         \
+  "s_bitset0_b64 %[" M "], %[p]\n\t"                                                                       \
+  "s_mov_b32 %[w], " N "\n\t"                                                                              \
+  "s_branch .Lend_%=\n"
+__device__ __forceinline__ void walk4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& w, uint32_t& p,
+                                      uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3, uint32_t& e) {
+  uint32_t t;
+  asm volatile(
+      "s_mov_b64 %[m0], 0\n\ts_mov_b64 %[m1], 0\n\ts_mov_b64 %[m2], 0\n\ts_mov_b64 %[m3], 0\n\t"
+      "s_nop 3\n\t"  // p may come from a VALU-written SGPR: four wait states before it selects a lane
+      "s_cmp_eq_u32 %[w], 1\n\ts_cbranch_scc1 .Lw1_%=\n\t"
+      "s_cmp_eq_u32 %[w], 2\n\ts_cbranch_scc1 .Lw2_%=\n\t"
+      "s_cmp_eq_u32 %[w], 3\n\ts_cbranch_scc1 .Lw3_%=\n"
+      HCIR_WALK_WINDOW("0", "c0", "m0", ".Lw1") HCIR_WALK_WINDOW("1", "c1", "m1", ".Lw2")
+      HCIR_WALK_WINDOW("2", "c2", "m2", ".Lw3") HCIR_WALK_WINDOW("3", "c3", "m3", ".Lpast")
+      ".Lpast_%=:\n\t"
+      "s_mov_b32 %[w], 4\n"
+      ".Lend_%=:\n\t"
+      : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [p] "+s"(p), [w] "+s"(w), [e] "=&s"(e),
+        [t] "=&s"(t)
+      : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3)
+      : "scc");
+}
+
+// inclusive wave scan on the DPP network: four shifts inside the rows of 16, two row broadcasts
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t s) {
+  return s + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t* total) {
+  uint32_t s = v;
+  s = dpp_add<0x111, 0xf>(s);  // row_shr:1
+  s = dpp_add<0x112, 0xf>(s);  // row_shr:2
+  s = dpp_add<0x114, 0xf>(s);  // row_shr:4
+  s = dpp_add<0x118, 0xf>(s);  // row_shr:8
+  s = dpp_add<0x142, 0xa>(s);  // row_bcast:15 into rows 1 and 3
+  s = dpp_add<0x143, 0xc>(s);  // row_bcast:31 into rows 2 and 3
+  *total = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);  // uniform: the write position stays scalar
   return s - v;
 }
 
+__device__ __forceinline__ void flush_units(Smem3* sm, uint8_t* raw, uint32_t& flushed, uint32_t wp, uint32_t need,
+                                            int lane) {
+  while (flushed + 1024 <= wp && flushed < need) {
+    *reinterpret_cast<u32x4*>(raw + flushed + lane * 16) =
+        *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(sm->ring + ((flushed + lane * 16) & (kRing - 1)));
+    flushed += 1024;
+  }
+}
+
+// ---- write one batch of symbols (lane k = symbol k, packed) into the ring.
+// One match: bytes [mp, mp + len) = bytes from mp - dist on, byte j repeating byte j mod dist when the copy overlaps
+// its own output (dist < len).  len <= 64: one lane per byte.
+__device__ __forceinline__ void copy_match(Smem3* sm, uint32_t mp, uint32_t len, uint32_t dist, float rdist, int lane,
+                                           float lanef) {
+  constexpr uint32_t M = kRing - 1;
+  uint32_t r = (uint32_t)lane - __umul24((uint32_t)(lanef * rdist), dist);  // lane mod dist; dist >= 64: quotient 0
+  r = min(r, r - dist);                                            // the float quotient can be one short
+  const uint8_t v = sm->ring[(mp - dist + r) & M];
+  const __attribute__((address_space(3))) uint8_t* base = sm->ring;
+  // lanes beyond the copy write to a dump byte of their own instead of toggling EXEC (a VALU -> EXEC round trip and a
+  // skip branch cost more than the whole copy)
+  const uint32_t off = (uint32_t)lane < len ? ((mp + lane) & M) : (uint32_t)(__builtin_offsetof(Smem, dump) + lane);
+  const_cast<__attribute__((address_space(3))) uint8_t*>(base)[off] = v;
+}
+
+// The rare ordered form: a source more than kRing - tot back could share its ring slot with a byte this batch writes
+// later, so the literals go in stream order, between the matches (distances close to 32 KB).
+__device__ __noinline__ void resolve_ordered(Smem3* sm, uint32_t sym, uint32_t mypos, uint64_t mm, uint64_t pend,
+                                             int lane) {
+  constexpr uint32_t M = kRing - 1;
+  mm = ((uint64_t)U((uint32_t)(mm >> 32)) << 32) | U((uint32_t)mm);
+  pend = ((uint64_t)U((uint32_t)(pend >> 32)) << 32) | U((uint32_t)pend);
+  while (mm) {
+    const int k = __builtin_ctzll(mm);
+    mm &= mm - 1;
+    const uint32_t ms = (uint32_t)__builtin_amdgcn_readlane((int)sym, k),
+                   mp = (uint32_t)__builtin_amdgcn_readlane((int)mypos, k);
+    const uint64_t before = pend & ((1ull << k) - 1);
+    if ((before >> lane) & 1) sm->ring[mypos & M] = (uint8_t)(sym >> 9);
+    pend &= ~before;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t dist = (ms >> 17) + 1u;
+    const float rd = 1.0f / (float)dist;
+    int32_t len = (int32_t)((ms >> 9) & 255u) + 3;
+    uint32_t at = mp;
+    do {
+      copy_match(sm, at, (uint32_t)len, dist, rd, lane, (float)lane);
+      __builtin_amdgcn_wave_barrier();
+      at += 64;
+      len -= 64;
+    } while (len > 0);
+  }
+  if ((pend >> lane) & 1) sm->ring[mypos & M] = (uint8_t)(sym >> 9);
+}
+
+// Returns the bytes produced; *bad: a distance reaches before the start of the data.
+__device__ __forceinline__ uint32_t resolve(Smem3* sm, uint32_t sym, uint32_t nsym, uint32_t wp, int lane, bool* bad) {
+  constexpr uint32_t M = kRing - 1;
+  const bool live = (uint32_t)lane < nsym, is_match = live && ((sym >> 7) & 1);
+  const uint32_t mylen = !live ? 0u : (is_match ? ((sym >> 9) & 255u) + 3u : 1u);
+  const uint32_t mydist = (sym >> 17) + 1u;
+  const float myrd = 1.0f / (float)mydist, lanef = (float)lane;
+  uint32_t tot;
+  const uint32_t mypos = wp + wave_excl_sum(mylen, &tot);
+  *bad = __ballot(is_match && mydist > mypos) != 0;  // PNG has no preset dictionary
+  uint64_t mm = __ballot(is_match);
+  const uint64_t lits = __ballot(live && !is_match);
+  if (__ballot(is_match && mydist + tot > (uint32_t)kRing) != 0) {
+    resolve_ordered(sm, sym, mypos, mm, lits, lane);
+    return tot;
+  }
+  if ((lits >> lane) & 1) sm->ring[mypos & M] = (uint8_t)(sym >> 9);  // every literal at once
+  while (mm) {                                                          // every match: lane-parallel copies
+    const int k = __builtin_ctzll(mm);
+    mm &= mm - 1;
+    const uint32_t ms = (uint32_t)__builtin_amdgcn_readlane((int)sym, k);
+    uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)mypos, k);
+    const float rd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myrd), k));
+    const uint32_t dist = (ms >> 17) + 1u;
+    int32_t len = (int32_t)((ms >> 9) & 255u) + 3;
+    do {  // 64 bytes at a time, front to back: the same copy
+      copy_match(sm, mp, (uint32_t)len, dist, rd, lane, lanef);
+      __builtin_amdgcn_wave_barrier();
+      mp += 64;
+      len -= 64;
+    } while (len > 0);
+  }
+  return tot;
+}
+
 __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
-  __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
-  __shared__ uint32_t lit_tab[1 << kLitRoot];
-  __shared__ uint32_t dist_tab[1 << kDistRoot];
-  __shared__ uint16_t lit_sorted[288], dist_sorted[32];
-  __shared__ Canon lit_cn, dist_cn;
-  // the code-length code is dead once the lengths are read: it borrows the distance table's storage
-  uint32_t* cl_tab = dist_tab;
-  uint16_t* cl_sorted = dist_sorted;
-  Canon* cl_cnp = &dist_cn;
-  __shared__ __attribute__((aligned(4))) uint8_t lens[320 + 16];
-  __shared__ __attribute__((aligned(4))) uint8_t cl_lens[20];
+  __shared__ __attribute__((aligned(16))) Smem smem;
+  Smem3* sm = (Smem3*)&smem;
 
   const int lane = (int)threadIdx.x;
   const int64_t img = blockIdx.x;
@@ -253,6 +628,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
 
   int err = 0;
   uint32_t bp = 16, wp = 0, flushed = 0;
+  STAMP_DECL;
   {  // RFC 1950: CM = 8, window <= 32 KB, header check, no preset dictionary
     const uint64_t h = in.peek(0);
     const uint32_t cmf = (uint32_t)h & 255, flg = ((uint32_t)h >> 8) & 255;
@@ -261,25 +637,23 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
 
   bool last = false, done = false;
   while (!err && !done && !last) {
-    if (bp + 3 > total_bits) {
-      err = 1;
-      break;
-    }
-    uint64_t win = in.peek(bp);
-    last = win & 1;
-    const uint32_t type = (uint32_t)(win >> 1) & 3;
-    bp += 3;
-    if (type == 3) {
-      err = 1;
-      break;
-    }
+    if (lane == 0) sm->u_bp = bp;
+    __syncthreads();
+    STAMP(0);
+    block_header(in.w, in.nwords, total_bits, sm, lane);
+    STAMP(1);
+    bp = U(sm->u_bp);
+    err = (int)U((uint32_t)sm->u_err);
+    last = U(sm->u_last) != 0;
+    const uint32_t type = U(sm->u_type);
+    if (err) break;
     if (type == 0) {  // stored: LEN, ~LEN at the next byte boundary, then LEN bytes as they are
       bp = (bp + 7) & ~7u;
       if (bp + 32 > total_bits) {
         err = 1;
         break;
       }
-      win = in.peek(bp);
+      const uint64_t win = in.peek(bp);
       uint32_t len = (uint32_t)win & 0xffff;
       if (len != (~(uint32_t)(win >> 16) & 0xffff)) {
         err = 1;
@@ -294,224 +668,158 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
       bp += len * 8;
       while (len && !done) {
         const uint32_t n = len < 1024 ? len : 1024;
-        for (uint32_t j = (uint32_t)lane; j < n; j += 64) ring[(wp + j) & (kRing - 1)] = stream[src + j];
+        for (uint32_t j = (uint32_t)lane; j < n; j += 64) sm->ring[(wp + j) & (kRing - 1)] = stream[src + j];
         wp += n;
         src += n;
         len -= n;
         __syncthreads();
-        while (flushed + 1024 <= wp && flushed < need) {
-          *reinterpret_cast<u32x4*>(raw + flushed + lane * 16) =
-              *reinterpret_cast<const u32x4*>(ring + ((flushed + lane * 16) & (kRing - 1)));
-          flushed += 1024;
-        }
+        flush_units(sm, raw, flushed, wp, need, lane);
         if (wp >= need) done = true;
       }
-      in.seek(bp >> 5);
       continue;
     }
-    // ---- code tables of this block
-    if (type == 1) {
-      for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-      __syncthreads();
-      build_table<kLitRoot, T_LIT, 288>(lens, 288, lit_tab, lit_sorted, &lit_cn, lane);
-      if (lane < 32) lens[lane] = 5;  // 30 and 31 are part of the fixed code and never valid (symbol_entry)
-      __syncthreads();
-      build_table<kDistRoot, T_DIST, 32>(lens, 32, dist_tab, dist_sorted, &dist_cn, lane);
-    } else {
-      if (bp + 14 > total_bits) {
-        err = 1;
-        break;
-      }
-      win = in.peek(bp);
-      const uint32_t hlit = ((uint32_t)win & 31) + 257, hdist = ((uint32_t)(win >> 5) & 31) + 1,
-                     hclen = ((uint32_t)(win >> 10) & 15) + 4;
-      bp += 14;
-      if (hlit > 286 || hdist > 30) {  // zlib: "too many length or distance symbols"
-        err = 1;
-        break;
-      }
-      win = in.peek(bp);  // up to 19 x 3 = 57 bits
-      if (lane < 19) {
-        // order of the code-length code lengths (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-        constexpr uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        uint32_t pos = 0;  // which transmitted slot carries symbol `lane`
-#pragma unroll
-        for (int i = 0; i < 19; ++i)
-          if (kOrder[i] == lane) pos = (uint32_t)i;
-        cl_lens[lane] = pos < hclen ? (uint8_t)((win >> (3 * pos)) & 7) : 0;
-      }
-      bp += 3 * hclen;
-      __syncthreads();
-      if (build_table<kClRoot, T_CL, 19>(cl_lens, 19, cl_tab, cl_sorted, cl_cnp, lane)) {
-        err = 1;
-        break;
-      }
-      const uint32_t total = hlit + hdist;
-      uint32_t i = 0, prev = 0;
-      while (i < total) {
-        if (bp > total_bits) {
-          err = 1;
-          break;
-        }
-        win = in.peek(bp);
-        const uint32_t e = __builtin_amdgcn_readfirstlane(cl_tab[(uint32_t)win & ((1 << kClRoot) - 1)]);
-        if (((e >> 4) & 7) != K_CL) {
-          err = 1;
-          break;
-        }
-        const uint32_t n = e & 15, sym = e >> 16;
-        uint32_t rep = 1, val = sym;
-        bp += n;
-        if (sym == 16) {
-          if (i == 0) {
-            err = 1;
-            break;
-          }
-          rep = 3 + ((uint32_t)(win >> n) & 3);
-          val = prev;
-          bp += 2;
-        } else if (sym == 17) {
-          rep = 3 + ((uint32_t)(win >> n) & 7);
-          val = 0;
-          bp += 3;
-        } else if (sym == 18) {
-          rep = 11 + ((uint32_t)(win >> n) & 127);
-          val = 0;
-          bp += 7;
-        }
-        if (i + rep > total) {
-          err = 1;
-          break;
-        }
-        for (uint32_t j = (uint32_t)lane; j < rep; j += 64) lens[i + j] = (uint8_t)val;
-        i += rep;
-        prev = val;
-      }
-      if (err) break;
-      __syncthreads();
-      if (lens[256] == 0) {  // zlib: "invalid code -- missing end-of-block"
-        err = 1;
-        break;
-      }
-      if (build_table<kLitRoot, T_LIT, 288>(lens, (int)hlit, lit_tab, lit_sorted, &lit_cn, lane)) {
-        err = 1;
-        break;
-      }
-      // the distance lengths follow the literal/length ones; move them to the front for the builder
-      uint8_t dl = 0;
-      if (lane < 32) dl = (uint32_t)lane < hdist ? lens[hlit + lane] : 0;
-      __syncthreads();
-      if (lane < 32) lens[lane] = dl;
-      __syncthreads();
-      if (build_table<kDistRoot, T_DIST, 32>(lens, (int)hdist, dist_tab, dist_sorted, &dist_cn, lane)) {
-        err = 1;
-        break;
-      }
-    }
-    // ---- the block's symbols, in batches of up to 64
+    // ---- the block's symbols.  Every pass looks up, in parallel, the symbol that would start at each of the next
+    // 256 bit positions; the serial part is only the walk from one symbol's start to the next, which marks the
+    // starts in a 64-bit mask per window.  Marked entries are appended to the symbol queue by their lanes; every
+    // 64 queued symbols are written to the ring as one batch.
+    uint32_t wbase = bp, pos = 0;  // pass origin; next symbol's start relative to it
+    uint32_t head = 0, tail = 0;   // symbol queue (sm->symq, a ring of 128)
     bool eob = false;
     while (!eob && !err && !done) {
-      uint32_t sym = 0;  // lane k: symbol k of the batch.  bit 31: match; literal: byte; match: len | (dist-1) << 9
-      uint32_t nsym = 0, outlen = 0;
-      while (nsym < 64) {
-        win = in.peek(bp);
-        uint32_t e = __builtin_amdgcn_readfirstlane(lit_tab[(uint32_t)win & ((1 << kLitRoot) - 1)]);
-        if (((e >> 4) & 7) == K_LONG) e = long_code<kLitRoot, T_LIT>((uint32_t)win, lit_sorted, &lit_cn);
-        const uint32_t kind = (e >> 4) & 7, n = e & 15;
-        uint32_t s;
-        if (kind == K_LIT) {
-          s = e >> 16;
-          outlen += 1;
-          bp += n;
-        } else if (kind == K_LEN) {
-          const uint32_t eb = (e >> 8) & 15;
-          const uint32_t len = (e >> 16) + ((uint32_t)(win >> n) & ((1u << eb) - 1));
-          uint32_t used = n + eb;
-          const uint32_t dbits = (uint32_t)(win >> used);
-          uint32_t d = __builtin_amdgcn_readfirstlane(dist_tab[dbits & ((1 << kDistRoot) - 1)]);
-          if (((d >> 4) & 7) == K_LONG) d = long_code<kDistRoot, T_DIST>(dbits, dist_sorted, &dist_cn);
-          if (((d >> 4) & 7) != K_DIST) {
-            err = 1;
-            break;
-          }
-          const uint32_t dn = d & 15, deb = (d >> 8) & 15;
-          const uint32_t dist = (d >> 16) + ((uint32_t)(win >> (used + dn)) & ((1u << deb) - 1));
-          used += dn + deb;
-          if (dist > wp + outlen) {  // before the start of the data (PNG has no preset dictionary)
-            err = 1;
-            break;
-          }
-          s = 0x80000000u | len | ((dist - 1) << 9);
-          outlen += len;
-          bp += used;
-        } else if (kind == K_EOB) {
-          bp += n;
-          eob = true;
-          break;
+      if (wbase + pos > total_bits) {  // ran past the end of the stream
+        err = 1;
+        break;
+      }
+      uint32_t ent[kSpan], lo[kSpan], hi[kSpan];
+      STAMP(0);
+      COUNT(2, 1);
+      {
+        const uint32_t k = in.cover(wbase >> 5);
+        uint32_t u[2 * kSpan + 3];
+        if (k + 2 * kSpan + 3 <= 64) {
+#pragma unroll
+          for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = (uint32_t)__builtin_amdgcn_readlane((int)in.v0, (int)(k + i));
         } else {
-          err = 1;
-          break;
+#pragma unroll
+          for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = in.word(k + i);
         }
-        sym = (uint32_t)lane == nsym ? s : sym;  // park symbol k in lane k
-        ++nsym;
-        if (wp + outlen >= need) {
-          done = true;
-          break;
+        const uint32_t o = (wbase & 31) + (uint32_t)lane, j = o >> 5, sh = o & 31;  // j in {0, 1, 2}
+#pragma unroll
+        for (int r = 0; r < kSpan; ++r) {
+          const uint32_t wa = j == 0 ? u[2 * r] : (j == 1 ? u[2 * r + 1] : u[2 * r + 2]);
+          const uint32_t wb = j == 0 ? u[2 * r + 1] : (j == 1 ? u[2 * r + 2] : u[2 * r + 3]);
+          const uint32_t wc = j == 0 ? u[2 * r + 2] : (j == 1 ? u[2 * r + 3] : u[2 * r + 4]);
+          lo[r] = __builtin_amdgcn_alignbit(wb, wa, sh);
+          hi[r] = __builtin_amdgcn_alignbit(wc, wb, sh);
         }
+        lookup_span(sm, lo, hi, ent);
       }
-      if (bp > total_bits) err = 1;  // ran past the end of the stream
-      if (err) break;
-      // ---- resolve the batch
-      const bool live = (uint32_t)lane < nsym, is_match = live && (sym >> 31);
-      const uint32_t mylen = !live ? 0u : (is_match ? (sym & 511u) : 1u);
-      uint32_t tot;
-      const uint32_t mypos = wp + wave_excl_sum(mylen, lane, &tot);
-      uint64_t pend = __ballot(live && !is_match);  // literals not yet in the ring
-      uint64_t mm = __ballot(is_match);
-      while (mm) {
-        const int k = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const uint64_t before = pend & ((1ull << k) - 1);
-        if (before) {
-          if ((before >> lane) & 1) ring[mypos & (kRing - 1)] = (uint8_t)sym;
-          pend &= ~before;
+      STAMP(2);
+      // ---- walk segments of the pass: one, plus one behind every serially decoded symbol
+      for (bool more = true; more;) {
+        uint64_t m0, m1, m2, m3;
+        uint32_t w = pos >> 6, p = pos & 63, e;
+        walk4(ent[0], ent[1], ent[2], ent[3], w, p, m0, m1, m2, m3, e);
+        STAMP(3);
+        pos = 64 * w + p;
+        bool stopped = w < 4;  // on stop entry e, at pos
+        // ---- the marked lanes append their symbols to the queue (a window the walk did not visit has no marks)
+        uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2),
+                 n3 = (uint32_t)__popcll(m3);
+        const uint32_t room = 127 - (tail - head);  // one slot stays free for a serially decoded symbol
+        if (n0 + n1 + n2 + n3 > room) {
+          // More starts than the queue takes (a pass of 1- and 2-bit codes).  n0 always fits (< 64 queued, <= 64
+          // marks): keep the windows that fit and walk on from the first start of the first one that does not.
+          const uint32_t d = n0 + n1 > room ? 1 : (n0 + n1 + n2 > room ? 2 : 3);
+          const uint64_t md = d == 1 ? m1 : (d == 2 ? m2 : m3);
+          pos = 64 * d + (uint32_t)__builtin_ctzll(md);
+          stopped = false;
+          if (d <= 1) m1 = 0, n1 = 0;
+          if (d <= 2) m2 = 0, n2 = 0;
+          m3 = 0, n3 = 0;
         }
-        const uint32_t ms = __builtin_amdgcn_readlane(sym, k), mp = __builtin_amdgcn_readlane(mypos, k);
-        const uint32_t len = ms & 511u, dist = ((ms >> 9) & 0xffffu) + 1u, src = mp - dist;
-        __builtin_amdgcn_wave_barrier();
-        if (dist >= len) {
-          for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
-            const uint8_t v = ring[(src + j) & (kRing - 1)];
-            ring[(mp + j) & (kRing - 1)] = v;
+        {
+          const uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, tail));
+          const uint32_t r1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, tail + n0));
+          const uint32_t r2 =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, tail + n0 + n1));
+          const uint32_t r3 =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, tail + n0 + n1 + n2));
+          // an unmarked lane writes to the dump slot behind the queue instead of toggling EXEC
+          sm->symq[(m0 >> lane) & 1 ? (r0 & 127) : 128] = ent[0];
+          sm->symq[(m1 >> lane) & 1 ? (r1 & 127) : 128] = ent[1];
+          sm->symq[(m2 >> lane) & 1 ? (r2 & 127) : 128] = ent[2];
+          sm->symq[(m3 >> lane) & 1 ? (r3 & 127) : 128] = ent[3];
+          tail += n0 + n1 + n2 + n3;
+        }
+        // ---- the entry the walk stopped on
+        if (stopped && ((e >> 7) & 3) == S_SLOW) {  // a long code: decode this one symbol serially, queue it
+          STAMP(6);
+          COUNT(3, 1);
+          const uint32_t r = pos >> 6;
+          const uint32_t l = r == 0 ? lo[0] : (r == 1 ? lo[1] : (r == 2 ? lo[2] : lo[3]));
+          const uint32_t h = r == 0 ? hi[0] : (r == 1 ? hi[1] : (r == 2 ? hi[2] : hi[3]));
+          e = U(lookup_slow((uint32_t)__builtin_amdgcn_readlane((int)l, (int)(pos & 63)),
+                            (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos & 63)), sm, lane));
+          if (e == ~0u) {
+            err = 1;
+            break;
           }
-        } else {  // the copy overlaps its own output: byte j repeats byte j mod dist
-          const float rd = 1.0f / (float)dist;
-          for (uint32_t j = (uint32_t)lane; j < len; j += 64) {
-            uint32_t r = j - (uint32_t)((float)j * rd) * dist;
-            if (r >= dist) r -= dist;
-            const uint8_t v = ring[(src + r) & (kRing - 1)];
-            ring[(mp + j) & (kRing - 1)] = v;
+          if (((e >> 7) & 3) != S_EOB) {
+            if (lane == 0) sm->symq[tail & 127] = e;
+            tail += 1;
+            pos += e & 63;
           }
+          STAMP(7);
         }
-        __builtin_amdgcn_wave_barrier();
+        if (stopped && ((e >> 7) & 3) == S_EOB) {
+          eob = true;
+          bp = wbase + pos + ((e >> 9) & 15);
+        }
+        more = !eob && pos < 64 * kSpan;
+        STAMP(6);
+        // ---- full batches go to the ring (and the last, partial one when the block ends)
+        while (tail - head >= 64 || (eob && tail != head)) {
+          WAVE_SYNC();
+          const uint32_t nsym = tail - head < 64 ? tail - head : 64;
+          const uint32_t sym = sm->symq[(head + lane) & 127];
+          COUNT(0, nsym);
+          COUNT(1, (uint32_t)__popcll(__ballot((uint32_t)lane < nsym && ((sym >> 7) & 1))));
+          bool bad;
+          wp += resolve(sm, sym, nsym, wp, lane, &bad);
+          head += nsym;
+          STAMP(4);
+          WAVE_SYNC();
+          flush_units(sm, raw, flushed, wp, need, lane);
+          STAMP(5);
+          if (bad) err = 1;
+          if (wp >= need) done = true;
+          if (bad || done) break;
+        }
+        if (err || done) break;
       }
-      if ((pend >> lane) & 1) ring[mypos & (kRing - 1)] = (uint8_t)sym;
-      wp += tot;
-      __syncthreads();
-      while (flushed + 1024 <= wp && flushed < need) {
-        *reinterpret_cast<u32x4*>(raw + flushed + lane * 16) =
-            *reinterpret_cast<const u32x4*>(ring + ((flushed + lane * 16) & (kRing - 1)));
-        flushed += 1024;
-      }
+      STAMP(6);
+      wbase += 64 * kSpan;
+      pos -= 64 * kSpan;
     }
+    if (bp > total_bits) err = 1;
   }
   if (!err && wp < need) err = 1;  // the stream ends before the last scanline the window needs
   if (!err && flushed < need) {    // the last, partial unit (the buffer has 1 KB of slack behind `need`)
     __syncthreads();
     *reinterpret_cast<u32x4*>(raw + flushed + lane * 16) =
-        *reinterpret_cast<const u32x4*>(ring + ((flushed + lane * 16) & (kRing - 1)));
+        *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(sm->ring + ((flushed + lane * 16) & (kRing - 1)));
   }
   if (lane == 0) a.status[img] = err ? HCIR_ERR_INVALID : HCIR_OK;
+#ifdef HCIR_PNG_STAMPS
+  STAMP(0);
+  if (lane == 0 && a.diag) {
+    uint64_t* d = a.diag + img * 16;
+    for (int i = 0; i < 8; ++i) d[i] = st_acc[i];
+    for (int i = 0; i < 4; ++i) d[8 + i] = st_n[i];
+    d[12] = wall_clock64();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -625,7 +933,7 @@ struct Plan {
   uint64_t raw_stride;
   int32_t max_x1;
   bool any[5];  // bytes-per-pixel classes present (index = bpp)
-  size_t bytes(int64_t b) const { return (size_t)b * raw_stride + (size_t)b * 4 + 512; }
+  size_t bytes(int64_t b) const { return (size_t)b * raw_stride + (size_t)b * 4 + 512 + (size_t)b * 128 + 256; }
 };
 
 int make_plan(const hcir_png_header* hdrs, int64_t b, int32_t win_h, int32_t win_w, Plan* p) {
@@ -739,6 +1047,7 @@ extern "C" int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_he
   a.raw = ws;
   a.raw_stride = p.raw_stride;
   a.status = status_dev ? status_dev : reinterpret_cast<int32_t*>(ws + (size_t)b * p.raw_stride);
+  a.diag = reinterpret_cast<uint64_t*>(ws + (((size_t)b * p.raw_stride + (size_t)b * 4 + 255) & ~(size_t)255));
   hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)b), dim3(64), 0, st, a);
   HCIR_LAUNCH_CHECK();
   const size_t lds = (size_t)p.max_x1 * 4;

@@ -23,10 +23,10 @@ def hair_like_files(n_synth=28, seed=7):
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:1024, 0:1024]
     for _ in range(n_synth):
-        base = rng.integers(0, 256, (48, 48, 3)).astype(np.uint8)
+        base = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
         a = np.asarray(Image.fromarray(base).resize((1024, 1024), Image.BICUBIC)).astype(np.int16)
-        a += rng.integers(-10, 10, a.shape, dtype=np.int16)  # strand-level texture
-        cy, cx, ry, rx = rng.integers(400, 624), rng.integers(400, 624), rng.integers(250, 480), rng.integers(200, 420)
+        a += rng.integers(-3, 4, a.shape, dtype=np.int16)  # strand-level texture; sizes come out like the four assets'
+        cy, cx, ry, rx = rng.integers(420, 604), rng.integers(420, 604), rng.integers(200, 400), rng.integers(160, 340)
         mask = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
         a[~mask] = 0
         b = io.BytesIO()

@@ -358,6 +358,31 @@ def other_configs(dev):
     return out
 
 
+def png_hair_files(n_synth=28, seed=7):
+    """1024 x 1024 8-bit RGB PNGs like the reference's hair-region crops: its four sample files (their bytes are in
+    tests/golden/png_streams.npz) + Pillow-written synthetic crops (a textured region on black), 220-670 KB each."""
+    import io
+    import numpy as np
+    from PIL import Image
+    z = np.load(os.path.join(ROOT, "tests", "golden", "png_streams.npz"))
+    names = [str(n) for n in z["names"]]
+    files = [z["data"][z["offsets"][i]:z["offsets"][i + 1]].tobytes() for i, n in enumerate(names)
+             if n.startswith("asset_")]
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    for _ in range(n_synth):
+        base = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
+        a = np.asarray(Image.fromarray(base).resize((1024, 1024), Image.BICUBIC)).astype(np.int16)
+        a += rng.integers(-3, 4, a.shape, dtype=np.int16)  # strand-level texture; sizes come out like the assets'
+        cy, cx, ry, rx = rng.integers(420, 604), rng.integers(420, 604), rng.integers(200, 400), rng.integers(160, 340)
+        mask = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+        a[~mask] = 0
+        b = io.BytesIO()
+        Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "PNG")
+        files.append(b.getvalue())
+    return files
+
+
 def main():
     # before ANY torch.cuda call: ROCr reads it when HIP initialises (the host driver only supports dmabuf IPC;
     # without it RCCL fails with hipIpcGetMemHandle: invalid argument)
@@ -560,39 +585,44 @@ def main():
     # side stream under the previous batch's compute; hcir_jpeg_decode_window_u8 reconstructs the CenterCrop(224)
     # windows on the device, hcir_knn_transform_u8 normalises them, then the same embed + top-k step.  Beside it: the
     # reference's decode (PIL = libjpeg-turbo, what HP/utils/dataloader.py:28-31 links) on every host core.
-    def decode_rates(n=6, distinct=48, cpu_sample=192):
+    def decode_rates(codec="jpeg", n=6, distinct=48, cpu_sample=192):
         import io
         import numpy as np
         from concurrent.futures import ThreadPoolExecutor
         from PIL import Image
-        from hcir import jpeg as hjpeg
         from hcir.transform import knn_transform_u8
-        rng = np.random.default_rng(7)
-        files = []
-        for _ in range(distinct):  # 1024 x 1024 baseline 4:2:0 like assets/samples/dummy/*.jpg (66-110 KB each)
-            base = rng.integers(0, 256, (40, 40, 3)).astype(np.uint8)
-            a = np.asarray(Image.fromarray(base).resize((1024, 1024), Image.BICUBIC)).astype(np.int16)
-            a[:, :512] += rng.integers(-12, 12, (1024, 512, 3), dtype=np.int16)
-            buf = io.BytesIO()
-            Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=88, subsampling=2)
-            files.append(buf.getvalue())
+        if codec == "jpeg":
+            from hcir import jpeg as hcodec
+            rng = np.random.default_rng(7)
+            files = []
+            for _ in range(distinct):  # 1024 x 1024 baseline 4:2:0 like assets/samples/dummy/*.jpg (66-110 KB each)
+                base = rng.integers(0, 256, (40, 40, 3)).astype(np.uint8)
+                a = np.asarray(Image.fromarray(base).resize((1024, 1024), Image.BICUBIC)).astype(np.int16)
+                a[:, :512] += rng.integers(-12, 12, (1024, 512, 3), dtype=np.int16)
+                buf = io.BytesIO()
+                Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=88, subsampling=2)
+                files.append(buf.getvalue())
+        else:
+            from hcir import png as hcodec
+            files = png_hair_files(distinct - 4)
+            distinct = len(files)
         batch_files = [files[i % distinct] for i in range(args.batch)]
         cores = host_cores()
         t1 = time.perf_counter()
-        staged = [hjpeg.stage_batch(batch_files, threads=cores) for _ in range(2)]
+        staged = [hcodec.stage_batch(batch_files, threads=cores) for _ in range(2)]
         stage_s = (time.perf_counter() - t1) / 2
         stream_bytes = staged[0].stream_bytes()
         file_bytes = sum(len(f) for f in batch_files)
         # parity of this very batch's first images against the reference decoder (PIL), then timing
         dev_staged = staged[0].to(dev)
-        win = hjpeg.decode_windows(dev_staged, 224, check_status=True)
+        win = hcodec.decode_windows(dev_staged, 224, check_status=True)
         ok = all(np.array_equal(win[i].cpu().numpy(),
                                 np.asarray(Image.open(io.BytesIO(batch_files[i])).convert("RGB"))[400:624, 400:624])
-                 for i in range(0, min(args.batch, distinct), 7))
+                 for i in range(0, min(args.batch, distinct), 7 if codec == "jpeg" else 3))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            hjpeg.decode_windows(dev_staged, 224)
+            hcodec.decode_windows(dev_staged, 224)
         e1.record()
         torch.cuda.synchronize()
         dec_ms = e0.elapsed_time(e1) / 5
@@ -613,8 +643,8 @@ def main():
                 if i >= 1:
                     j = (i - 1) % 2
                     main.wait_event(copied[j])
-                    sb = hjpeg.StagedBatch(devb[j], staged[j].b, staged[j].status, staged[j]._host_headers)
-                    step(xin=knn_transform_u8(hjpeg.decode_windows(sb, 224)))
+                    sb = hcodec.StagedBatch(devb[j], staged[j].b, staged[j].status, staged[j]._host_headers)
+                    step(xin=knn_transform_u8(hcodec.decode_windows(sb, 224)))
                     consumed[j].record(main)
             drain()
 
@@ -630,27 +660,38 @@ def main():
                 return np.asarray(im.convert("RGB"))[400:624, 400:624].copy()
 
         sample = batch_files[:cpu_sample]
-        with ThreadPoolExecutor(cores) as ex:  # PIL's decoder releases the GIL
+        with ThreadPoolExecutor(cores) as ex:  # PIL's decoders release the GIL
             list(ex.map(pil_window, sample[:cores]))
             t1 = time.perf_counter()
             list(ex.map(pil_window, sample))
             pil_rate = len(sample) / (time.perf_counter() - t1)
-        return {"img_per_s": rate, "byte_exact_vs_pillow": bool(ok),
-                "note": "same step fed from JPEG files (1024x1024 baseline 4:2:0, synthetic): host staging by "
-                        "loader threads (timed separately below), blob H2D on a side stream, device Huffman + IDCT "
-                        "+ upsample/colour of the CenterCrop(224) window, device knn_transform; not `value`",
+        if codec == "jpeg":
+            note = ("same step fed from JPEG files (1024x1024 baseline 4:2:0, synthetic): host staging by loader "
+                    "threads (timed separately below), blob H2D on a side stream, device Huffman + IDCT + "
+                    "upsample/colour of the CenterCrop(224) window, device knn_transform; not `value`")
+            lib = "libjpeg-turbo"
+        else:
+            note = ("same step fed from PNG files, the format of every hair-region crop the reference lists "
+                    "(HP/data/data_train.csv: *_hair.png): 1024x1024 8-bit RGB, the reference's four sample crops "
+                    "(tests/golden/png_streams.npz) + Pillow-written synthetic crops of the same size range "
+                    "(textured region on black); host staging = chunk walk + CRC-32 + IDAT copy by loader threads, "
+                    "blob H2D on a side stream, device inflate (rows 0..623) + unfilter + CenterCrop(224) window, "
+                    "device knn_transform; not `value`")
+            lib = "zlib + PNG unfilter"
+        return {"img_per_s": rate, "byte_exact_vs_pillow": bool(ok), "note": note,
                 "device_decode_ms_per_batch": dec_ms, "device_decode_img_per_s": args.batch / (dec_ms * 1e-3),
                 "compressed_stream_GBps": stream_bytes / (dec_ms * 1e-3) / 1e9,
                 "file_bytes_per_image": file_bytes / args.batch,
                 "host_stage_img_per_s": args.batch / stage_s, "host_stage_threads": cores,
                 "cpu_baseline": {"value": pil_rate, "unit": "images/sec", "cores": cores, "kind": "reference",
-                                 "sample": f"{len(sample)} of the same files: PIL (libjpeg-turbo) full decode + "
+                                 "sample": f"{len(sample)} of the same files: PIL ({lib}) full decode + "
                                            f"CenterCrop(224) on {cores} threads"}}
 
     pcie = None
     sweep = None
     yard = None
     decode_inc = None
+    decode_inc_png = None
     configs = None
     if world == 1 and not args.no_extras:
         pcie = {"note": "same step, inputs copied from pinned host memory on a side stream under the previous "
@@ -679,7 +720,8 @@ def main():
         step(xin=x)   # back to the bench batch shape (engine buffers)
         drain()
         yard = vendor_yardstick(args.batch, dev)
-        decode_inc = decode_rates()
+        decode_inc = decode_rates("jpeg")
+        decode_inc_png = decode_rates("png", distinct=32)
         step(xin=x)
         drain()
         with contextlib.redirect_stdout(sys.stderr):  # model constructors print; stdout stays ONE JSON line
@@ -759,6 +801,7 @@ def main():
             "phase_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
             "pcie_inclusive": pcie,
             "decode_inclusive": decode_inc,
+            "decode_inclusive_png": decode_inc_png,
             "configs": configs,
             "batch_sweep": sweep,
         }

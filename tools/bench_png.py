@@ -16,23 +16,7 @@ from PIL import Image
 from hcir import png
 
 
-def hair_like_files(n_synth=28, seed=7):
-    z = np.load(os.path.join(ROOT, "tests", "golden", "png_streams.npz"))
-    names = [str(n) for n in z["names"]]
-    files = [z["data"][z["offsets"][i]:z["offsets"][i + 1]].tobytes() for i, n in enumerate(names) if n.startswith("asset_")]
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:1024, 0:1024]
-    for _ in range(n_synth):
-        base = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
-        a = np.asarray(Image.fromarray(base).resize((1024, 1024), Image.BICUBIC)).astype(np.int16)
-        a += rng.integers(-3, 4, a.shape, dtype=np.int16)  # strand-level texture; sizes come out like the four assets'
-        cy, cx, ry, rx = rng.integers(420, 604), rng.integers(420, 604), rng.integers(200, 400), rng.integers(160, 340)
-        mask = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
-        a[~mask] = 0
-        b = io.BytesIO()
-        Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(b, "PNG")
-        files.append(b.getvalue())
-    return files
+from bench import png_hair_files as hair_like_files  # the bench's own file set
 
 
 def main():

@@ -109,6 +109,10 @@ SIGNATURES = {
     "hcir_png_stage_batch": (c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_vp, c_vp, c_i32]),
     "hcir_png_workspace_bytes": (c_sz, [c_vp, c_i64, c_i32, c_i32]),
     "hcir_png_decode_window_u8": (c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "hcir_resize_bicubic_ksize": (c_i32, [c_i32, c_i32]),
+    "hcir_resize_bicubic_coeffs": (c_int, [c_i32, c_i32, c_vp, c_vp]),
+    "hcir_resize_crop_workspace_bytes": (c_sz, [c_vp, c_i64, c_i32, c_i32]),
+    "hcir_resize_crop_bicubic_u8": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
 }
 
 

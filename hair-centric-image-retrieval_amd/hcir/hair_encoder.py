@@ -7,9 +7,12 @@
   .retrieve_similar_images(query_embedding, all_embeddings, all_paths, top_k=5)  :180-198
   .load_embeddings / .check_embeddings_exist  (embeddings.npy + image_paths.txt)  :144-163
 
-Image pipeline (:43-50): Resize(224, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize.  Resize and crop
-run on the host with PIL (the decode is host PIL anyway); the crop window travels as RGB8 and ToTensor +
-Normalize run on the device (hcir_knn_transform_u8, bit-identical to the torchvision arithmetic).
+Image pipeline (:43-50): Resize(224, bicubic) -> CenterCrop(224) -> ToTensor -> Normalize, all on the device:
+the loader workers only READ the files; PNG and baseline-JPEG files are decoded whole by hcir_png_decode_window_u8 /
+hcir_jpeg_decode_window_u8 (window = image), hcir_resize_crop_bicubic_u8 applies Pillow's bicubic resize (byte-exact)
+and the centre crop, hcir_knn_transform_u8 ToTensor + Normalize (bit-identical to the torchvision arithmetic).
+A file outside the device decoders' subsets (bmp, webp, progressive JPEG, 16-bit PNG ...) is decoded by PIL on the
+host, as the reference does, and joins the batch as RGB8 in front of the device resize.
 `ImageFolder` restates torchvision.datasets.ImageFolder's directory contract (class sub-folders in sorted
 order, files in sorted order, its extension list); torchvision is not a dependency.
 
@@ -72,6 +75,23 @@ def resize_shorter_side(image, size: int = 224):
     new_short, new_long = size, int(size * long / short)
     nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
     return image.resize((nw, nh), Image.BICUBIC)
+
+
+class _FileBytes:
+    """Dataset of raw file contents (uint8 tensors) in ImageFolder order: what a loader worker does is read()."""
+
+    def __init__(self, samples):
+        self.samples = samples
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        return torch.from_numpy(np.fromfile(self.samples[i][0], dtype=np.uint8))
+
+
+def _identity(items):
+    return items
 
 
 class FeatureExtractor:
@@ -137,23 +157,58 @@ class HairEncoder:
 
     @staticmethod
     def _window_u8(im) -> torch.Tensor:
+        """Host form of the window (PIL resize + crop): what the device path is tested against."""
         return center_window_u8(resize_shorter_side(im, 224), 224)
+
+    def device_windows(self, files) -> torch.Tensor:
+        """Compressed files (bytes / uint8 arrays) -> the transform's RGB8 windows [B, 224, 224, 3] on the device:
+        whole-image device decode per (codec, size) group, then ONE device resize + crop over the batch."""
+        import io
+        from PIL import Image
+        from . import jpeg, png, resize
+        if not str(self.device).startswith("cuda"):
+            raise RuntimeError("HairEncoder.device_windows runs on a HIP device only (no CPU fallback)")
+        raw = [jpeg._as_u8(f) for f in files]
+        groups = {}
+        for i, a in enumerate(raw):
+            with Image.open(io.BytesIO(a)) as im:  # header parse only
+                kind = "png" if im.format == "PNG" else ("jpeg" if im.format == "JPEG" else "host")
+                groups.setdefault((kind, im.size[1], im.size[0]), []).append(i)
+        images = [None] * len(raw)
+        for (kind, h, w), idx in groups.items():
+            sub = [raw[i] for i in idx]
+            whole = None
+            host = list(range(len(sub)))
+            if kind != "host":
+                mod = png if kind == "png" else jpeg
+                staged = mod.stage_batch(sub, threads=min(8, len(sub)))
+                host = staged.rejected
+                if len(host) < len(sub):
+                    whole = mod.decode_windows(staged.to(self.device), (h, w), _skip_rejected_check=True)
+            for k, i in enumerate(idx):
+                if k in host:  # the reference's own decoder for this file
+                    with Image.open(io.BytesIO(sub[k])) as im:
+                        images[i] = torch.from_numpy(np.asarray(im.convert("RGB")).copy()).to(self.device)
+                else:
+                    images[i] = whole[k]
+        return resize.resize_center_crop(images, 224)
 
     def extract_dataset_features(self, data_path, batch_size=64, num_workers=8, save_dir="embeddings"):
         """Embed every image of an ImageFolder tree, save embeddings.npy + image_paths.txt (:103-142).
-        Decode / resize / crop in DataLoader workers (RGB8 windows), ToTensor + Normalize + ViT on the device;
-        embeddings stay in HBM until the single copy back at the end."""
+        DataLoader workers read the files; decode, Resize, CenterCrop, ToTensor, Normalize and the ViT run on the
+        device; embeddings stay in HBM until the single copy back at the end."""
         from torch.utils.data import DataLoader
         print(f"Loading dataset from: {data_path}")
-        dataset = ImageFolder(data_path, transform=self._window_u8)
-        loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+        dataset = ImageFolder(data_path)
+        loader = DataLoader(_FileBytes(dataset.samples), batch_size=batch_size, shuffle=False, num_workers=num_workers,
+                            collate_fn=_identity)
         feats, all_paths = [], []
         with torch.no_grad():
-            for wins, _ in loader:
-                x = knn_transform_u8(wins.to(self.device, non_blocking=True))
+            for files in loader:
+                x = knn_transform_u8(self.device_windows(files))
                 feats.append(self.extract_features(x).float().clone())   # the engine re-uses its buffers
                 start_idx = len(all_paths)
-                all_paths.extend([dataset.samples[i][0] for i in range(start_idx, start_idx + wins.size(0))])
+                all_paths.extend([dataset.samples[i][0] for i in range(start_idx, start_idx + len(files))])
         all_embeddings = torch.cat(feats, 0).cpu().numpy()
         self.save_embeddings(all_embeddings, all_paths, save_dir)
         print(f"Saved {all_embeddings.shape[0]} embeddings and paths to {save_dir}")
@@ -161,10 +216,7 @@ class HairEncoder:
 
     def encode_single_image(self, image_path):
         """One image -> embedding (np.ndarray [D]) (:165-178)."""
-        from PIL import Image
-        with Image.open(image_path) as im:
-            win = self._window_u8(im.convert("RGB"))
-        x = knn_transform_u8(win.to(self.device))
+        x = knn_transform_u8(self.device_windows([np.fromfile(image_path, dtype=np.uint8)]))
         return self.extract_features(x).float().cpu().numpy()[0]
 
     # ---- retrieval ----

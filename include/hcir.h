@@ -581,6 +581,40 @@ int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_header* hdrs_
                               int32_t win_w, uint8_t* out, int32_t* status_dev, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ *
+ * Resize(224, bicubic) + CenterCrop(224) on the device: the input transform of the hair_retrieval path,
+ *   transforms.Resize(224, interpolation=3) -> CenterCrop(224)        src/models/hair_encoder.py:44-48
+ * applied in extract_dataset_features (:116-117) and encode_single_image (:175).  torchvision hands a PIL image to
+ * Image.resize(size, BICUBIC): Pillow's two-pass separable resampler (third-party, not under /root/reference;
+ * Pillow 12.2 src/libImaging/Resample.c): per output pixel a window of the bicubic kernel (a = -0.5) widened by the
+ * scale (antialias), coefficients normalised in double and rounded to 22-bit fixed point, horizontal pass first,
+ * an 8-bit clipped intermediate, then the vertical pass.  The coefficient tables are computed on the HOST with the
+ * same double arithmetic; the two passes run on the device in the same integer arithmetic: bytes equal Pillow's.
+ * Only the pixels the crop window needs are computed.
+ * ------------------------------------------------------------------ */
+/* HOST.  Taps per output pixel (Pillow's ksize) of one axis resampled from in_size to out_size; 0 on bad sizes. */
+int32_t hcir_resize_bicubic_ksize(int32_t in_size, int32_t out_size);
+/* HOST.  bounds [2 * out_size] = (first source index, tap count) per output index; kk [out_size * ksize] = the
+ * 22-bit fixed-point coefficients (precompute_coeffs + normalize_coeffs_8bpc). */
+int hcir_resize_bicubic_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk);
+
+typedef struct hcir_resize_job { /* one image of a batch */
+  uint64_t src_offset;          /* bytes from `src`: RGB8 rows of the source image                              */
+  int64_t src_pitch;            /* bytes between its rows                                                        */
+  int32_t src_h, src_w;
+  int32_t out_h, out_w;         /* size after the resize (before the crop)                                       */
+  int32_t crop_top, crop_left;  /* origin of the window inside the resized image (negative: zero padding)       */
+  int32_t coef_h, coef_v;       /* int32 offsets into `coef`: [bounds (2 * out) | kk (out * ksize)] of each axis; */
+  int32_t ksize_h, ksize_v;     /* -1 offset: that axis is not resampled (out == in)                             */
+} hcir_resize_job;
+
+/* HOST.  Workspace bytes: the horizontal pass's 8-bit intermediate of every image. */
+size_t hcir_resize_crop_workspace_bytes(const hcir_resize_job* jobs_host, int64_t b, int32_t win_h, int32_t win_w);
+/* src, coef, jobs_dev: DEVICE; jobs_host: the same records on the host (sizing).  out [b][win_h][win_w][3] uint8. */
+int hcir_resize_crop_bicubic_u8(const uint8_t* src, const int32_t* coef, const hcir_resize_job* jobs_dev,
+                                const hcir_resize_job* jobs_host, int64_t b, int32_t win_h, int32_t win_w,
+                                uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

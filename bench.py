@@ -344,10 +344,55 @@ def other_configs(dev):
                 "fraction_of_slots_compared": float(safe.double().mean())}
         return res
 
+    def hair_retrieval(b=256, n=4):
+        """src/hair_retrieval.py's embedding pass (HairEncoder.extract_dataset_features, src/models/hair_encoder.py:
+        103-142): PNG files -> whole-image device decode -> Pillow-exact bicubic Resize(224) -> CenterCrop ->
+        Normalize -> models_vit ViT-B/16 CLS.  Beside it the reference's host transform of the same files."""
+        import io
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        from PIL import Image
+        from hcir.hair_encoder import HairEncoder
+        from hcir.transform import knn_transform_u8
+        torch.manual_seed(0)
+        enc = HairEncoder(None, "vit_base_patch16", device=str(dev))
+        files = png_hair_files(12)
+        batch = [np.frombuffer(files[i % len(files)], np.uint8) for i in range(b)]
+
+        def one():
+            with torch.no_grad():
+                return enc.extract_features(knn_transform_u8(enc.device_windows(batch)))
+        ref = enc._window_u8(Image.open(io.BytesIO(files[0])).convert("RGB"))
+        exact = bool(torch.equal(enc.device_windows(batch[:1])[0].cpu(), ref))
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one()
+        torch.cuda.synchronize()
+        rate = b * n / (time.perf_counter() - t0)
+        cores = host_cores()
+
+        def host(fb):
+            return enc._window_u8(Image.open(io.BytesIO(fb)).convert("RGB"))
+        sample = [files[i % len(files)] for i in range(96)]
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(host, sample[:cores]))
+            t0 = time.perf_counter()
+            list(ex.map(host, sample))
+            host_rate = len(sample) / (time.perf_counter() - t0)
+        return {"img_per_s": rate, "batch": b, "window_byte_exact_vs_pillow": exact,
+                "note": "1024x1024 PNG files (bench's hair-crop set) -> embeddings, files resident in host memory; "
+                        "host staging included (8 threads), decode + resize + crop + normalise + ViT on the device",
+                "cpu_baseline": {"value": host_rate, "unit": "images/sec (input transform only)", "cores": cores,
+                                 "kind": "reference",
+                                 "sample": f"{len(sample)} of the same files: PIL decode + Resize(224, bicubic) + "
+                                           f"CenterCrop(224) on {cores} threads, no model"}}
+
     keep = vit_engine.DEFAULT_RESID_DTYPE
     vit_engine.DEFAULT_RESID_DTYPE = torch.float16
     try:
-        for name, fn in (("c2", c2), ("c5", c5), ("c3_train_step", c3)):
+        for name, fn in (("c2", c2), ("c5", c5), ("hair_retrieval", hair_retrieval), ("c3_train_step", c3)):
             try:
                 out[name] = fn()
             except Exception as e:  # noqa: BLE001 - reported, never fatal for the bench line

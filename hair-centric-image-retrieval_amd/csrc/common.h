@@ -57,21 +57,28 @@ __device__ __forceinline__ float wave_max(float v) {
 // `s_waitcnt vmcnt(0)` before the barrier that publishes the stage.  VMEM operations the compiler does not know of
 // only make the vmcnt(N) it computes for its own loads stricter (returns are in order), never wrong.
 // Source = wave-uniform base (SGPR pair) + 32-bit per-lane byte offset; destination = wave-uniform LDS byte address
-// (lds_addr() of the 1 KB the 64 lanes fill).
+// (lds_addr() of the 1 KB the 64 lanes fill).  M0 is on the clobber list: the compiler may not keep a value of its own
+// in M0 across a transfer (a builtin LDS-DMA, movrel, readlane through m0 in the same kernel).
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 __device__ __forceinline__ void lds_dma16(const void* src_base, uint32_t src_off, uint32_t lds_wave_addr) {
   const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(src_off), "s"(src_base), "s"(m)
-               : "memory");
+               : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma16_nt(const void* src_base, uint32_t src_off, uint32_t lds_wave_addr) {  // non-temporal
+  const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(src_off), "s"(src_base), "s"(m)
+               : "memory", "m0");
 }
 // Same, per-lane 64-bit source address (no wave-uniform base at hand).
 __device__ __forceinline__ void lds_dma16_v(const void* gsrc, uint32_t lds_wave_addr) {
   const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(m) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma16_v_nt(const void* gsrc, uint32_t lds_wave_addr) {   // non-temporal
   const uint32_t m = __builtin_amdgcn_readfirstlane(lds_wave_addr);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(m) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gsrc), "s"(m)
+               : "memory", "m0");
 }

@@ -694,6 +694,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
     // (every CU of an XCD re-reads them from L2)
 #ifndef HCIR_GEMM_BUILTIN_DMA   // the transfer issued outside the compiler's view (common.h lds_dma16): +1.3 % over
                                 // the layer against the builtin (qkv +2.6 %), which stays behind this flag for A/B runs
+#ifdef HCIR_GEMM_A_NT   // EXPERIMENT (build flag): activation rows with the non-temporal policy, so that the streamed
+                        // A panels do not push the W panels out of the XCD's L2
+    if (i >= 4)
+      lds_dma16_nt(abase + issue_kc * 128, soff[i],
+                   lds_addr(lds) + slot * G256::STAGE_BYTES + ((tid & ~63) + G256::NT * i) * 16);
+    else
+#endif
     lds_dma16((i < 4 ? wbase : abase) + issue_kc * 128, soff[i],
               lds_addr(lds) + slot * G256::STAGE_BYTES + ((tid & ~63) + G256::NT * i) * 16);
 #else
@@ -873,6 +880,7 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
   f32x4 bias[NPASS][NB], scale[NPASS][NB];
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
+    if constexpr (kF16) break;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int n = nbase + pass * FPP + rchunk * (kF16 ? 8 : 4) + 4 * j;
@@ -883,20 +891,33 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
         scale[pass][j] = *reinterpret_cast<const f32x4*>(g.scale + n);
     }
   }
-  float ln_rs[NIT], ln_mean[MTH];
+  // fp16 outputs: bias / scale / activation / LayerNorm fold run on the ACCUMULATOR side, in fp32, before the ONE
+  // rounding to fp16, exactly as in gemm_epilogue256_lds_impl (the earlier form rounded the raw accumulator first:
+  // a second rounding, one fp16 ulp away from the 256 x 256 kernel's result)
+  constexpr bool kScaleA = kF16 && (EPI == HCIR_EPI_AFFINE_RELU_F16 || kResidH);
+  f32x4 biasA[kF16 ? NTW : 1], scaleA[kScaleA ? NTW : 1];
+  if constexpr (kF16) {
+    const bool has_scale = kScaleA && (EPI == HCIR_EPI_AFFINE_RELU_F16 || g.scale != nullptr);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int n = nbase + 16 * t + 4 * q16;
+      biasA[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (g.bias) biasA[t] = *reinterpret_cast<const f32x4*>(g.bias + n);
+      if constexpr (kScaleA) {
+        scaleA[t] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (has_scale) scaleA[t] = *reinterpret_cast<const f32x4*>(g.scale + n);
+      }
+    }
+  }
+  float ln_rs[MTH], ln_mean[MTH];
   f32x4 c1a[NTW];
   if constexpr (kLn) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      int64_t mm = m0h + it * 8 + rrow;
-      mm = mm < g.m ? mm : g.m - 1;
-      ln_rs[it] = g.ln_stats[2 * mm + 1];
-    }
 #pragma unroll
     for (int mt = 0; mt < MTH; ++mt) {
       int64_t mm = m0h + 16 * mt + r16;
       mm = mm < g.m ? mm : g.m - 1;
       ln_mean[mt] = g.ln_stats[2 * mm];
+      ln_rs[mt] = g.ln_stats[2 * mm + 1];
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) c1a[t] = *reinterpret_cast<const f32x4*>(g.ln_c1 + nbase + 16 * t + 4 * q16);
@@ -904,19 +925,29 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (kLn) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(ln_rs[it]));
-#pragma unroll
-    for (int mt = 0; mt < MTH; ++mt) asm volatile("" : "+v"(ln_mean[mt]));
+    for (int mt = 0; mt < MTH; ++mt) {
+      asm volatile("" : "+v"(ln_rs[mt]));
+      asm volatile("" : "+v"(ln_mean[mt]));
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) launder(c1a[t]);
   }
+  if constexpr (kF16) {
 #pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass)
+    for (int t = 0; t < NTW; ++t) {
+      launder(biasA[t]);
+      if constexpr (kScaleA) launder(scaleA[t]);
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if constexpr (kF16) break;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       launder(bias[pass][j]);
       launder(scale[pass][j]);
     }
+  }
 
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -929,13 +960,33 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
         for (int q = 0; q < 4; ++q) {
           const int nt = 4 * pass + q;
           f16x4 o;
-          if constexpr (kLn) {
+          float xs[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)__builtin_fmaf(-ln_mean[mt], c1a[nt][e], acc[nt][mt0 + mt][e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)acc[nt][mt0 + mt][e];
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[nt][mt0 + mt][e];
+            const float bb = biasA[nt][e];
+            if constexpr (kLn) {
+              // out = rstd[m] (acc - mean[m] c1[n]) + bias[n]: centered first (cancellation when |mean| >> std)
+              x = __builtin_fmaf(ln_rs[mt], __builtin_fmaf(-ln_mean[mt], c1a[nt][e], x), bb);
+            } else if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
+              x = fmaxf(__builtin_fmaf(x, scaleA[nt][e], bb), 0.f);
+            } else if constexpr (kResidH) {
+              x = scaleA[nt][e] * (x + bb);
+            } else {
+              x += bb;
+            }
+            xs[e] = x;
           }
+          if constexpr (kGelu) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
+              xs[e] = y[0];
+              xs[e + 1] = y[1];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (_Float16)xs[e];
           const int chunk = 2 * q + (q16 >> 1);
           *reinterpret_cast<f16x4*>(region + row * 128 + ((chunk ^ (row & 7)) << 4) + 8 * (q16 & 1)) = o;
         }
@@ -968,33 +1019,13 @@ __device__ __forceinline__ void gemm_epilogue16_lds_impl(const GemmArgs& g, cons
         for (int u = 0; u < UB; ++u) {
           const int row = (it0 + u) * 8 + rrow;
           const f16x8 v = *reinterpret_cast<const f16x8*>(region + row * 128 + ((rchunk ^ (row & 7)) << 4));
+          // the image already holds the finished fp16 values; the fp16 residual is one packed add per pair (the
+          // exact sum of two fp16 numbers, rounded once)
           f16x8 o;
-          float xs[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = (float)v[e];
-            const float bb = bias[pass][e >> 2][e & 3];
-            if constexpr (EPI == HCIR_EPI_AFFINE_RELU_F16) {
-              x = fmaxf(__builtin_fmaf(x, scale[pass][e >> 2][e & 3], bb), 0.f);
-            } else if constexpr (kResidH) {
-              x = __builtin_fmaf(scale[pass][e >> 2][e & 3], x + bb, (float)oldh[u][e]);
-            } else if constexpr (kLn) {
-              x = __builtin_fmaf(ln_rs[it0 + u], x, bb);
-            } else {
-              x += bb;
-            }
-            xs[e] = x;
-          }
-          if constexpr (kGelu) {
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-              const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
-              xs[e] = y[0];
-              xs[e + 1] = y[1];
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (_Float16)xs[e];
+          if constexpr (kResidH)
+            o = v + oldh[u];
+          else
+            o = v;
           const int64_t m = m0h + row;
           if (FULL || m < g.m)
             __builtin_nontemporal_store(o, reinterpret_cast<f16x8*>(static_cast<_Float16*>(g.out) + m * g.ldo + n));

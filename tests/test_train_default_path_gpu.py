@@ -54,8 +54,16 @@ def test_positive_transform_draws_like_torchvision(hcir_built):
     assert torch.equal(pt(x), pt.apply(x, a, s))
 
 
-@pytest.mark.parametrize("b", [8, 64, 200])
+@pytest.mark.parametrize("b", [8, 64, 256, 1024])
 def test_projection_head_train_mode_vs_torch_modules(hcir_built, b):
+    """The train-mode head on the HIP path against a float64 ground truth (torch modules in double, same parameters).
+    Every output and gradient is held to TWICE the error of a float64 computation whose GEMM operands are rounded to
+    fp16 (tests/_fp64.py: the rounding the operand format forces), and, where the batch statistics are well
+    conditioned (b >= 256), to 1.5e-2 outright (2.5e-2 for the BatchNorm parameters): just above that emulation's own error.  b = 8 stays as the smoke case of a nearly singular BatchNorm."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _fp64 import fp64_head
     from hcir.main_backbone import SimCLRProjectionHead
     torch.manual_seed(3)
     ref = SimCLRProjectionHead(768, 768, 512).train()
@@ -68,34 +76,49 @@ def test_projection_head_train_mode_vs_torch_modules(hcir_built, b):
     hip = copy.deepcopy(ref).cuda().train()
     x = torch.randn(b, 768)
     w = torch.randn(b, 512)
-    xr = x.clone().requires_grad_(True)
-    out_r = ref(xr)                       # CPU tensors take the torch modules (fp32)
-    (out_r * w).sum().backward()
-    xh = x.cuda().requires_grad_(True)
-    out_h = hip(xh)
-    (out_h * w.cuda()).sum().backward()
-    # BatchNorm's backward subtracts batch means of the gradient, and the bias gradients are sums over the batch
-    # only: over 8 / 64 / 200 samples the fp16 rounding of the GEMM operands shows as 3e-2 / 1.7e-2 / 1.4e-2 relative
-    # (measured; two BatchNorm backwards in a row), cosine > 0.9998
-    gtol = 5e-2 if b < 32 else 2.5e-2
-    assert _rel(out_h.cpu(), out_r.detach()) <= 3e-3
-    assert _rel(xh.grad.cpu(), xr.grad) <= gtol
-    for (n, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters()):
-        assert ph.grad is not None and _rel(ph.grad.cpu(), pr.grad) <= gtol, n
-    for (n, br), (_, bh) in zip(ref.named_buffers(), hip.named_buffers()):
+
+    def run(model, xin, wgt):
+        xin = xin.clone().requires_grad_(True)
+        out = model(xin)
+        (out * wgt).sum().backward()
+        return out.detach(), xin.grad, [p.grad for p in model.parameters()]
+
+    truth = fp64_head(ref, "cuda")
+    emul = fp64_head(ref, "cuda", half_operands=True)
+    o64, dx64, g64 = run(truth, x.double().cuda(), w.double().cuda())
+    oe, dxe, ge = run(emul, x.double().cuda(), w.double().cuda())
+    oh, dxh, gh = run(hip, x.cuda(), w.cuda())
+    names = ["out", "dx"] + [n for n, _ in hip.named_parameters()]
+    worst = 0.0
+    for n, t64, te, th in zip(names, [o64, dx64] + g64, [oe, dxe] + ge, [oh, dxh] + gh):
+        e_hip, e_emu = _rel(th, t64), _rel(te, t64)
+        if e_emu > 1e-5:  # (a gradient that no GEMM touches - the last bias: a plain sum - has no format error to compare)
+            worst = max(worst, e_hip / e_emu)
+        assert e_hip <= 2.0 * e_emu + 1e-6, f"{n}: HIP {e_hip:.3e} vs fp64, half-operand emulation {e_emu:.3e}"
+        if b >= 256:
+            # outright, where the batch statistics are well conditioned.  The bars sit just above what the half-operand
+            # emulation itself shows against float64 (measured: dx 1.18e-2 at b = 1024 for the emulation AND for the
+            # kernel, to four digits; BatchNorm gains / biases 0.8-1.6e-2): the error is the operand format's
+            bar = 2.5e-2 if (".1." in n or ".4." in n) else 1.5e-2
+            assert e_hip <= bar, f"{n}: {e_hip:.3e} at batch {b} (half-operand emulation {e_emu:.3e})"
+        elif n == "out":
+            assert e_hip <= 3e-3
+    print(f"b={b}: worst HIP / emulation error ratio {worst:.2f}")
+    # running statistics against the float64 modules
+    for (n, br), (_, bh) in zip(truth.named_buffers(), hip.named_buffers()):
         if "num_batches" in n:
             assert int(bh) == int(br) == 1
         else:
-            assert torch.allclose(bh.cpu(), br, rtol=2e-3, atol=2e-4), n
+            assert torch.allclose(bh.double(), br, rtol=2e-3, atol=2e-4), n
     # under no_grad (the momentum head inside the step): same values, statistics updated again
     with torch.no_grad():
         o2 = hip(x.cuda())
-    assert _rel(o2.cpu(), out_r.detach()) <= 3e-3 and int(hip.layers[1].num_batches_tracked) == 2
+    assert _rel(o2, o64) <= 3e-3 and int(hip.layers[1].num_batches_tracked) == 2
     # a tiny incoming gradient (no GradScaler) must not vanish in the fp16 operands
     hip.zero_grad(set_to_none=True)
     (hip(x.cuda()) * (w.cuda() * 1e-6)).sum().backward()
-    g = hip.layers[0].weight.grad.cpu() / 1e-6
-    assert _rel(g, ref.layers[0].weight.grad) <= 2 * gtol
+    g = hip.layers[0].weight.grad / 1e-6
+    assert _rel(g, g64[0]) <= 2.0 * max(_rel(ge[0], g64[0]), 2e-3) + 2e-3
 
 
 def test_hard_negative_schedule_and_cache(hcir_built):

@@ -199,6 +199,85 @@ def test_attention_backward(b, t, heads):
         assert _rel(got[..., sl], qd.grad[..., sl]) <= 2e-2
 
 
+@pytest.mark.parametrize("b,t,heads", [(26, 197, 12), (48, 197, 12), (30, 193, 12), (70, 65, 8)])
+def test_attention_backward_persistent_loop(b, t, heads):
+    """More (image, head) items than workgroups (the grid is min(items, 256)): the loop-carried paths of the persistent
+    kernel run — the counted wait on the next item's fragments, the transfers issued under pass 2, the dQ stores
+    deferred behind the next barrier.  312, 576, 360 (t = 193: a last wave with ONE live row) and 560 items.
+    Checked against the fp64 definition, and bit for bit against the same kernel fed ONE image at a time (12 or 8
+    items: one item per workgroup, nothing carried from item to item)."""
+    from hcir import train_ops as T
+    g = torch.Generator().manual_seed(50 + b)
+    qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 0.8).half()
+    qkv[b // 2, 3, :64] *= 4.0
+    dout = torch.randn(b, t, heads * 64, generator=g).half()
+    scale = 64 ** -0.5
+    out = torch.empty(b, t, heads * 64, dtype=torch.float16, device="cuda")
+    lse = torch.empty(b, heads, t, dtype=torch.float32, device="cuda")
+    qc, dc = qkv.cuda(), dout.cuda()
+    T.attn_fwd_lse(qc, b, t, heads, scale, out, lse)
+    dqkv = torch.full((b, t, 3 * heads * 64), float("nan"), dtype=torch.float16, device="cuda")
+    T.attn_bwd(qc, out, dc, lse, b, t, heads, scale, dqkv)
+    assert torch.isfinite(dqkv).all()
+    # fp64 definition, a few images at a time (the 48-image case would hold 48 x 12 x 197 x 197 doubles four times)
+    for i0 in range(0, b, 8):
+        sl = slice(i0, min(i0 + 8, b))
+        qd = qkv[sl].double().requires_grad_(True)
+        ref_out = _attn_ref(qd, qd.shape[0], t, heads, scale)
+        ref_out.backward(dout[sl].double())
+        assert (out[sl].cpu().double() - ref_out.detach()).abs().max() <= 4e-3
+        got = dqkv[sl].cpu().double()
+        err = (got - qd.grad).abs().max().item()
+        assert err <= 1.5e-2 * qd.grad.abs().max().item() + 2e-3, (i0, err)
+        for s0 in range(3):
+            c = slice(s0 * heads * 64, (s0 + 1) * heads * 64)
+            assert _rel(got[..., c], qd.grad[..., c]) <= 2e-2
+    # one image at a time: every workgroup handles exactly one item
+    for i in sorted({0, 1, 256 // heads, 256 // heads + 1, b // 2, b - 1}):
+        o1 = torch.empty(1, t, heads * 64, dtype=torch.float16, device="cuda")
+        l1 = torch.empty(1, heads, t, dtype=torch.float32, device="cuda")
+        T.attn_fwd_lse(qc[i:i + 1].contiguous(), 1, t, heads, scale, o1, l1)
+        assert torch.equal(o1[0], out[i]) and torch.equal(l1[0], lse[i])
+        d1 = torch.full((1, t, 3 * heads * 64), float("nan"), dtype=torch.float16, device="cuda")
+        T.attn_bwd(qc[i:i + 1].contiguous(), o1, dc[i:i + 1].contiguous(), l1, 1, t, heads, scale, d1)
+        assert torch.equal(d1[0], dqkv[i]), f"image {i}: the persistent loop changes the result"
+
+
+@pytest.mark.parametrize("b,t,heads", [(26, 197, 12), (50, 193, 12)])
+def test_attention_cls_backward_persistent_loop(b, t, heads):
+    """hcir_attn_cls_fwd_lse / hcir_attn_cls_bwd (the last block's attention for the CLS row alone) with more items
+    than workgroups: against the fp64 definition and bit for bit against one image at a time."""
+    from hcir import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(90 + b)
+    qkv = (torch.randn(b, t, 3 * heads * 64, generator=g) * 0.8).half()
+    dout = torch.randn(b, heads * 64, generator=g).half()
+    scale = 64 ** -0.5
+
+    def run(q, do, n):
+        o = torch.empty(n, heads * 64, dtype=torch.float16, device="cuda")
+        l = torch.empty(n, heads, dtype=torch.float32, device="cuda")
+        _lib.check(L.hcir_attn_cls_fwd_lse(q.data_ptr(), n, t, heads, 64, scale, o.data_ptr(), l.data_ptr(), st), "fwd")
+        d = torch.full((n, t, 3 * heads * 64), float("nan"), dtype=torch.float16, device="cuda")
+        _lib.check(L.hcir_attn_cls_bwd(q.data_ptr(), o.data_ptr(), do.data_ptr(), l.data_ptr(), n, t, heads, 64, scale,
+                                       d.data_ptr(), st), "bwd")
+        return o, l, d
+    qc, dc = qkv.cuda(), dout.cuda()
+    out, lse, dqkv = run(qc, dc, b)
+    assert torch.isfinite(dqkv).all()
+    qd = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qd, b, t, heads, scale)[:, 0]
+    ref.backward(dout.double())
+    assert (out.cpu().double() - ref.detach()).abs().max() <= 4e-3
+    got = dqkv.cpu().double()
+    err = (got - qd.grad).abs().max().item()
+    assert err <= 1.5e-2 * qd.grad.abs().max().item() + 2e-3, err
+    for i in sorted({0, 256 // heads, 256 // heads + 1, b - 1}):
+        o1, l1, d1 = run(qc[i:i + 1].contiguous(), dc[i:i + 1].contiguous(), 1)
+        assert torch.equal(o1[0], out[i]) and torch.equal(l1[0], lse[i]) and torch.equal(d1[0], dqkv[i])
+
+
 def test_triplet_and_mse_losses():
     from hcir import train_ops as T
     g = torch.Generator().manual_seed(6)

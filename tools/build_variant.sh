@@ -14,7 +14,7 @@ for o in "$src"/*.o; do
   b=$(basename "$o" .o)
   if echo " $files " | grep -q " $b.hip "; then
     extra=""; [ "$b" = attn_bwd ] && extra="-fno-slp-vectorize"   # as in csrc/Makefile
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function $extra $flags -c "$src/$b.hip" -o "$tmp/$b.o"
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -Wno-inline-asm $extra $flags -c "$src/$b.hip" -o "$tmp/$b.o"
     objs="$objs $tmp/$b.o"
   else
     objs="$objs $o"

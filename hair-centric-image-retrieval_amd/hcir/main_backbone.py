@@ -156,7 +156,7 @@ class ViTWrapper(nn.Module):
         pooled_patches = eng.patch_mean(tok, final_norm=True)
         return cls_token, pooled_patches
 
-    def forward_cls(self, x: torch.Tensor, l2_normalize: bool = False, want_f16: bool = False):
+    def forward_cls(self, x: torch.Tensor, l2_normalize: bool = False, want_f16: bool = False, slot: int = 0):
         """CLS embedding only (what SHAM2.extract_features consumes); optionally fused
         F.normalize and an fp16 copy for the similarity scan.  Differentiable when autograd is on and the
         parameters require grad (then fp32 [B, D], no fused normalise)."""
@@ -165,7 +165,7 @@ class ViTWrapper(nn.Module):
                 raise NotImplementedError("the differentiable forward returns the plain fp32 class token")
             return vit_cls_with_grad(self.trainer(x.device), x)
         eng = self.engine(x.device)
-        tok = eng.forward_tokens(x, cls_only_last=True)   # only the class token is consumed
+        tok = eng.forward_tokens(x, cls_only_last=True, slot=slot)   # only the class token is consumed
         return eng.cls_embedding(tok, final_norm=True, l2_normalize=l2_normalize, want_f16=want_f16)
 
 

@@ -144,8 +144,10 @@ class VitEngine:
             self.prof.mark(name)
 
     # -- buffers ---------------------------------------------------------------
-    def _buffers(self, b: int, t: int):
-        key = (b, t)
+    def _buffers(self, b: int, t: int, slot: int = 0):
+        """Work buffers of one forward in flight.  `slot`: which of several forwards in flight at once (one per HIP
+        stream, hcir.pipeline.StreamPipeline); buffers of another shape are dropped."""
+        key = (b, t, slot)
         bufs = self._bufs.get(key)
         if bufs is None:
             m, d, dev = b * t, self.dim, self.device
@@ -163,11 +165,12 @@ class VitEngine:
                 stats_part=torch.empty((max(d // 64, 1), m, 2), dtype=torch.float32, device=dev),
                 stats=torch.empty((m, 2), dtype=torch.float32, device=dev),
             )
-            self._bufs = {key: bufs}  # keep one shape resident
+            self._bufs = {k: v for k, v in self._bufs.items() if k[:2] == (b, t)}  # keep one shape resident
+            self._bufs[key] = bufs
         return bufs
 
     # -- forward ---------------------------------------------------------------
-    def forward_tokens(self, x: torch.Tensor, cls_only_last: bool = False) -> torch.Tensor:
+    def forward_tokens(self, x: torch.Tensor, cls_only_last: bool = False, slot: int = 0) -> torch.Tensor:
         """x fp32 [B,3,H,W] on the HIP device -> token buffer [B,T,D] in resid_dtype (engine-owned).
 
         cls_only_last: the caller consumes only the class token (extract_features).  The last block
@@ -190,7 +193,7 @@ class VitEngine:
             raise HcirError(f"image gives {t} tokens but pos_embedding has {self.pos.shape[0]}")
         L, d, m = self.L, self.dim, b * t
         st = torch.cuda.current_stream(x.device).cuda_stream
-        w = self._buffers(b, t)
+        w = self._buffers(b, t, slot)
         tok, ln, qkv, att, hid = w["tok"], w["ln"], w["qkv"], w["att"], w["hid"]
         check(L.hcir_patch_embed(x.data_ptr(), b, c, hh, ww, ps, self.conv_w.data_ptr(), self.conv_w.shape[1],
                                  self.conv_b.data_ptr(), self.cls.data_ptr(), self.pos.data_ptr(),

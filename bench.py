@@ -745,7 +745,7 @@ def main():
             from hcir.pipeline import StreamPipeline
             xb = x[:bsz].contiguous()
             pipe = StreamPipeline(vit, gallery, args.topk, depth=2, device=dev)
-            for _ in range(4):
+            for _ in range(12):  # both streams' allocator pools and workspaces warm
                 pipe.submit(xb)
             pipe.drain()
             torch.cuda.synchronize()

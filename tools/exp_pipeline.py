@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where a 64-image step's time goes with one and with two batches in flight: embed only / embed + search over a
+1M-row gallery; host enqueue time per step (no GPU wait) beside the wall time."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "hair-centric-image-retrieval_amd")]
+import torch
+import torch.nn.functional as F
+from hcir import vit_engine
+from hcir.gallery import ResidentGallery
+from hcir.main_backbone import SHAM2
+from hcir.pipeline import StreamPipeline
+
+vit_engine.DEFAULT_RESID_DTYPE = torch.float16
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+torch.manual_seed(0)
+model = SHAM2("vit_b_16").cuda().eval()
+vit = model.backbone
+x = torch.randn(b, 3, 224, 224, device="cuda")
+
+
+class NoSearch:
+    def search_begin(self, e32, k, q16=None):
+        class H:
+            def finish(self_inner):
+                return e32
+        return H()
+
+
+def run(gal, depth, n=60):
+    pipe = StreamPipeline(vit, gal, 10, depth=depth)
+    for _ in range(6):
+        pipe.submit(x)
+    pipe.drain()
+    torch.cuda.synchronize()
+    host = 0.0
+    t0 = time.perf_counter()
+    for _ in range(n):
+        h0 = time.perf_counter()
+        pipe.submit(x)
+        host += time.perf_counter() - h0
+    pipe.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / n * 1e3, host / n * 1e3
+
+
+for name, gal in (("embed only", NoSearch()),
+                  ("embed + top-10 over 10k", ResidentGallery(F.normalize(torch.randn(10_000, 768, device="cuda"), dim=1))),
+                  ("embed + top-10 over 1M", ResidentGallery(F.normalize(torch.randn(1_000_000, 768, device="cuda"), dim=1)))):
+    for depth in (1, 2, 3):
+        ms, host = run(gal, depth)
+        print(f"{name:28s} depth {depth}: {ms:6.3f} ms/step = {b / ms * 1e3:7.0f} img/s   (submit() host time {host:5.3f} ms, "
+              "includes waiting for the slot's previous batch)", flush=True)

@@ -4,7 +4,8 @@
 // src/models/hair_encoder.py:108,169 (PIL), for the format every hair-region crop it lists is stored in
 // (HairPretraining/data/data_train.csv: *_hair.png; assets/hair_region_only/*.png).
 //
-// Two kernels, one 64-lane wavefront per image each (a batch is hundreds of images; a wave per SIMD):
+// Two kernels; per image the first runs two 64-lane wavefronts (a decoder and a copier), the second one (a batch is
+// hundreds of images: a wave or two per SIMD):
 //
 //  png_inflate_kernel   zlib/deflate (RFC 1950/1951) up to the last scanline the window needs.
 //    * The compressed words sit in two VGPRs (lane i = word base+i, base+64+i), fetched 256 B at a time; the
@@ -33,7 +34,8 @@ namespace {
 
 constexpr int kRing = 32768;  // deflate's maximum distance: the ring never needs to be larger (the reads of a copy
                               // come before its writes; literals that could alias a far source are written in order)
-constexpr int kLitRoot = 10, kDistRoot = 9, kClRoot = 7;
+constexpr int kLitRoot = 10, kDistRoot = 8, kClRoot = 7;
+constexpr uint32_t kQueue = 256;  // symbol queue entries (a ring) between the decoding and the copying wavefront
 constexpr uint32_t K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_DIST = 4, K_LONG = 5, K_CL = 6;
 enum { T_CL = 0, T_LIT = 1, T_DIST = 2 };
 // A decoded symbol, packed: bits 0-6 the walk's step = stream bits it takes (code + extra bits; a match: length AND
@@ -95,7 +97,10 @@ struct Smem {
   uint16_t lit_sorted[288], dist_sorted[32];
   uint8_t lens[320 + 12];
   uint8_t cl_lens[20];
-  uint32_t symq[128 + 1];         // decoded symbols waiting for their batch of 64 (a ring) + a dump slot
+  uint32_t symq[kQueue + 1];      // decoded symbols on their way to the copying wavefront (a ring) + a dump slot
+  uint32_t q_tail, q_eos;         // written by the decoding wavefront: entries published; 1 = no more will come
+  uint32_t q_head, q_stop;        // written by the copying wavefront: entries consumed; 1 = stop decoding
+  int32_t errs[2];
   uint8_t dump[64];               // where the lanes beyond a copy's length write
   uint32_t u_bp, u_last, u_type;  // wave-uniform state handed between block_header() and the kernel
   int32_t u_err;
@@ -180,13 +185,13 @@ __device__ __forceinline__ int build_table(const __attribute__((address_space(3)
     cn->count[lane] = c;
     cn->offs[lane] = of;
   }
-  __syncthreads();
+  WAVE_SYNC();
 #pragma unroll
   for (int c = 0; c < kChunks; ++c) {
     const int s = c * 64 + lane;
     if (mylen[c]) sorted[cn->offs[mylen[c]] + myrank[c]] = (uint16_t)s;
   }
-  __syncthreads();
+  WAVE_SYNC();
   // every ROOT-bit index finds the code it starts with: the first L bits (stream order = most significant code
   // bit first) form the L-bit number c; c is a code of length L iff first[L] <= c < first[L] + count[L]
   for (int e = lane; e < (1 << ROOT); e += 64) {
@@ -199,7 +204,7 @@ __device__ __forceinline__ int build_table(const __attribute__((address_space(3)
     }
     tab[e] = v;
   }
-  __syncthreads();
+  WAVE_SYNC();
   return 0;
 }
 
@@ -290,10 +295,10 @@ __device__ __noinline__ void block_header(const uint32_t* words, uint32_t nwords
     if (type == 0) break;  // stored: the kernel copies the bytes
     if (type == 1) {
       for (int s = lane; s < 288; s += 64) sm->lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-      __syncthreads();
+      WAVE_SYNC();
       build_table<kLitRoot, T_LIT, 288>(sm->lens, 288, sm->lit_tab, sm->lit_sorted, &sm->lit_cn, lane);
       if (lane < 32) sm->lens[lane] = 5;  // 30 and 31 are part of the fixed code and never valid (symbol_entry)
-      __syncthreads();
+      WAVE_SYNC();
       build_table<kDistRoot, T_DIST, 32>(sm->lens, 32, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane);
       break;
     }
@@ -320,7 +325,7 @@ __device__ __noinline__ void block_header(const uint32_t* words, uint32_t nwords
       sm->cl_lens[lane] = pos < hclen ? (uint8_t)((win >> (3 * pos)) & 7) : 0;
     }
     bp += 3 * hclen;
-    __syncthreads();
+    WAVE_SYNC();
     if (build_table<kClRoot, T_CL, 19>(sm->cl_lens, 19, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane)) {
       err = 1;
       break;
@@ -367,7 +372,7 @@ __device__ __noinline__ void block_header(const uint32_t* words, uint32_t nwords
       prev = val;
     }
     if (err) break;
-    __syncthreads();
+    WAVE_SYNC();
     if (U(sm->lens[256]) == 0) {  // zlib: "invalid code -- missing end-of-block"
       err = 1;
       break;
@@ -379,19 +384,19 @@ __device__ __noinline__ void block_header(const uint32_t* words, uint32_t nwords
     // the distance lengths follow the literal/length ones; move them to the front for the builder
     uint8_t dl = 0;
     if (lane < 32) dl = (uint32_t)lane < hdist ? sm->lens[hlit + lane] : 0;
-    __syncthreads();
+    WAVE_SYNC();
     if (lane < 32) sm->lens[lane] = dl;
-    __syncthreads();
+    WAVE_SYNC();
     if (build_table<kDistRoot, T_DIST, 32>(sm->lens, (int)hdist, sm->dist_tab, sm->dist_sorted, &sm->dist_cn, lane)) err = 1;
   } while (false);
-  __syncthreads();
+  WAVE_SYNC();
   if (lane == 0) {
     sm->u_bp = bp;
     sm->u_err = err;
     sm->u_last = last;
     sm->u_type = type;
   }
-  __syncthreads();
+  WAVE_SYNC();
 }
 
 // ---- lane-parallel lookup: the symbol that WOULD start at this lane's bit position (lo/hi = the 64 stream bits
@@ -597,48 +602,64 @@ __device__ __forceinline__ uint32_t resolve(Smem3* sm, uint32_t sym, uint32_t ns
   return tot;
 }
 
-__global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
-  __shared__ __attribute__((aligned(16))) Smem smem;
-  Smem3* sm = (Smem3*)&smem;
+// ---- the two wavefronts of an image.  Wave 0 DECODES: block headers and code tables, the lane-parallel lookup, the
+// walk, the queue appends.  Wave 1 COPIES: batches of 64 queued symbols into the ring, finished units to HBM.  They meet
+// in the symbol queue only (LDS): the decoder publishes q_tail behind its entries, the copier q_head behind its
+// reads - LDS operations of one wavefront complete in order, so a counter read after it was written shows the data
+// written before it.  Neither wave ever waits inside a barrier for the other; the waits are bounded polls.
+// Plain (volatile) LDS accesses between compiler-only fences: no s_waitcnt on the vector-memory counter, which a
+// workgroup-scope release would put in front of the store (the decoder's stream prefetch and the copier's write-out
+// stores are in flight and have nothing to do with the queue).
+__device__ __forceinline__ uint32_t lds_load(const __attribute__((address_space(3))) uint32_t* p) {
+  const uint32_t v = *reinterpret_cast<const volatile __attribute__((address_space(3))) uint32_t*>(p);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return U(v);
+}
+__device__ __forceinline__ void lds_store(__attribute__((address_space(3))) uint32_t* p, uint32_t v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) *reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>(p) = v;
+}
+constexpr uint32_t kPollLimit = 1u << 22;  // polls of ~64 cycles: a wave that waits longer than this gives up (corrupt)
 
-  const int lane = (int)threadIdx.x;
-  const int64_t img = blockIdx.x;
-  const hcir_png_header* hp = reinterpret_cast<const hcir_png_header*>(a.blob) + img;
-  const int32_t width = hp->width, height = hp->height, bpp = hp->bpp;
-  if (width <= 0) {
-    if (lane == 0) a.status[img] = HCIR_OK;  // a file the stager rejected: skipped
-    return;
-  }
-  png_host::Win wn;
-  png_host::window(width, height, a.win_h, a.win_w, wn);
-  const uint32_t need = wn.y1 > 0 && wn.x1 > wn.x0 ? (uint32_t)wn.y1 * (1u + (uint32_t)width * (uint32_t)bpp) : 0u;
-  if (need == 0) {
-    if (lane == 0) a.status[img] = HCIR_OK;
-    return;
-  }
-  const uint8_t* stream = a.blob + hp->stage_offset;
-  const uint32_t stream_bytes = hp->stream_bytes, total_bits = stream_bytes * 8u;
-  uint8_t* raw = a.raw + (uint64_t)img * a.raw_stride;
-
+__device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const uint8_t* stream, uint32_t stream_bytes,
+                                           int lane, uint64_t* diag) {
+  const uint32_t total_bits = stream_bytes * 8u;
   Words in;
   in.w = reinterpret_cast<const uint32_t*>(stream);
   in.nwords = (stream_bytes + 3) / 4 + 4;  // staged with >= 16 zero bytes behind the stream
   in.lane = lane;
   in.seek(0);
-
   int err = 0;
-  uint32_t bp = 16, wp = 0, flushed = 0;
+  uint32_t bp = 16, tail = 0, head = 0;  // head: the copier's progress as last seen
+  bool stop = false;
   STAMP_DECL;
   {  // RFC 1950: CM = 8, window <= 32 KB, header check, no preset dictionary
     const uint64_t h = in.peek(0);
     const uint32_t cmf = (uint32_t)h & 255, flg = ((uint32_t)h >> 8) & 255;
     if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20) || stream_bytes < 2) err = 1;
   }
-
-  bool last = false, done = false;
-  while (!err && !done && !last) {
+  // free queue slots (one stays free); refreshes the copier's counters when fewer than `want` are known to be free
+  auto room_for = [&](uint32_t want) -> uint32_t {
+    uint32_t room = kQueue - 1 - (tail - head);
+    for (uint32_t polls = 0; room < want && !stop; ++polls) {
+      head = lds_load(&sm->q_head);
+      stop = lds_load(&sm->q_stop) != 0;
+      room = kQueue - 1 - (tail - head);
+      if (room >= want || stop) break;
+      if (polls > kPollLimit) {
+        err = 1;
+        stop = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    return room;
+  };
+  bool last = false;
+  while (!err && !stop && !last) {
     if (lane == 0) sm->u_bp = bp;
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(0);
     block_header(in.w, in.nwords, total_bits, sm, lane);
     STAMP(1);
@@ -647,7 +668,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
     last = U(sm->u_last) != 0;
     const uint32_t type = U(sm->u_type);
     if (err) break;
-    if (type == 0) {  // stored: LEN, ~LEN at the next byte boundary, then LEN bytes as they are
+    if (type == 0) {  // stored: LEN, ~LEN at the next byte boundary, then LEN bytes: queued as literals, 64 at a time
       bp = (bp + 7) & ~7u;
       if (bp + 32 > total_bits) {
         err = 1;
@@ -666,26 +687,23 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
         break;
       }
       bp += len * 8;
-      while (len && !done) {
-        const uint32_t n = len < 1024 ? len : 1024;
-        for (uint32_t j = (uint32_t)lane; j < n; j += 64) sm->ring[(wp + j) & (kRing - 1)] = stream[src + j];
-        wp += n;
+      while (len && !stop && !err) {
+        const uint32_t n = len < 64 ? len : 64;
+        if (room_for(64) < 64) break;
+        if ((uint32_t)lane < n) sm->symq[(tail + lane) & (kQueue - 1)] = pack_lit(0, stream[src + lane]);
+        tail += n;
+        lds_store(&sm->q_tail, tail, lane);
         src += n;
         len -= n;
-        __syncthreads();
-        flush_units(sm, raw, flushed, wp, need, lane);
-        if (wp >= need) done = true;
       }
       continue;
     }
     // ---- the block's symbols.  Every pass looks up, in parallel, the symbol that would start at each of the next
     // 256 bit positions; the serial part is only the walk from one symbol's start to the next, which marks the
-    // starts in a 64-bit mask per window.  Marked entries are appended to the symbol queue by their lanes; every
-    // 64 queued symbols are written to the ring as one batch.
+    // starts in a 64-bit mask per window.  Marked entries are appended to the symbol queue by their lanes.
     uint32_t wbase = bp, pos = 0;  // pass origin; next symbol's start relative to it
-    uint32_t head = 0, tail = 0;   // symbol queue (sm->symq, a ring of 128)
     bool eob = false;
-    while (!eob && !err && !done) {
+    while (!eob && !err && !stop) {
       if (wbase + pos > total_bits) {  // ran past the end of the stream
         err = 1;
         break;
@@ -726,10 +744,14 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
         // ---- the marked lanes append their symbols to the queue (a window the walk did not visit has no marks)
         uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1), n2 = (uint32_t)__popcll(m2),
                  n3 = (uint32_t)__popcll(m3);
-        const uint32_t room = 127 - (tail - head);  // one slot stays free for a serially decoded symbol
+        // one slot beyond the marks for a serially decoded symbol; at least a window's worth always (n0 <= 64)
+        uint32_t want = n0 + n1 + n2 + n3 + 1;
+        want = want < 65 ? 65 : (want > kQueue - 1 ? kQueue - 1 : want);
+        const uint32_t room = room_for(want) - 1;
+        if (stop) break;
         if (n0 + n1 + n2 + n3 > room) {
-          // More starts than the queue takes (a pass of 1- and 2-bit codes).  n0 always fits (< 64 queued, <= 64
-          // marks): keep the windows that fit and walk on from the first start of the first one that does not.
+          // More starts than the queue takes right now (a pass of 1- and 2-bit codes, or a slow copier).  n0 fits:
+          // keep the windows that fit and walk on from the first start of the first one that does not.
           const uint32_t d = n0 + n1 > room ? 1 : (n0 + n1 + n2 > room ? 2 : 3);
           const uint64_t md = d == 1 ? m1 : (d == 2 ? m2 : m3);
           pos = 64 * d + (uint32_t)__builtin_ctzll(md);
@@ -746,10 +768,10 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
           const uint32_t r3 =
               __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, tail + n0 + n1 + n2));
           // an unmarked lane writes to the dump slot behind the queue instead of toggling EXEC
-          sm->symq[(m0 >> lane) & 1 ? (r0 & 127) : 128] = ent[0];
-          sm->symq[(m1 >> lane) & 1 ? (r1 & 127) : 128] = ent[1];
-          sm->symq[(m2 >> lane) & 1 ? (r2 & 127) : 128] = ent[2];
-          sm->symq[(m3 >> lane) & 1 ? (r3 & 127) : 128] = ent[3];
+          sm->symq[(m0 >> lane) & 1 ? (r0 & (kQueue - 1)) : kQueue] = ent[0];
+          sm->symq[(m1 >> lane) & 1 ? (r1 & (kQueue - 1)) : kQueue] = ent[1];
+          sm->symq[(m2 >> lane) & 1 ? (r2 & (kQueue - 1)) : kQueue] = ent[2];
+          sm->symq[(m3 >> lane) & 1 ? (r3 & (kQueue - 1)) : kQueue] = ent[3];
           tail += n0 + n1 + n2 + n3;
         }
         // ---- the entry the walk stopped on
@@ -766,60 +788,129 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(PngBatch a) {
             break;
           }
           if (((e >> 7) & 3) != S_EOB) {
-            if (lane == 0) sm->symq[tail & 127] = e;
+            if (lane == 0) sm->symq[tail & (kQueue - 1)] = e;
             tail += 1;
             pos += e & 63;
           }
           STAMP(7);
         }
+        lds_store(&sm->q_tail, tail, lane);
+        COUNT(0, n0 + n1 + n2 + n3);
         if (stopped && ((e >> 7) & 3) == S_EOB) {
           eob = true;
           bp = wbase + pos + ((e >> 9) & 15);
         }
         more = !eob && pos < 64 * kSpan;
         STAMP(6);
-        // ---- full batches go to the ring (and the last, partial one when the block ends)
-        while (tail - head >= 64 || (eob && tail != head)) {
-          WAVE_SYNC();
-          const uint32_t nsym = tail - head < 64 ? tail - head : 64;
-          const uint32_t sym = sm->symq[(head + lane) & 127];
-          COUNT(0, nsym);
-          COUNT(1, (uint32_t)__popcll(__ballot((uint32_t)lane < nsym && ((sym >> 7) & 1))));
-          bool bad;
-          wp += resolve(sm, sym, nsym, wp, lane, &bad);
-          head += nsym;
-          STAMP(4);
-          WAVE_SYNC();
-          flush_units(sm, raw, flushed, wp, need, lane);
-          STAMP(5);
-          if (bad) err = 1;
-          if (wp >= need) done = true;
-          if (bad || done) break;
-        }
-        if (err || done) break;
       }
-      STAMP(6);
       wbase += 64 * kSpan;
       pos -= 64 * kSpan;
     }
     if (bp > total_bits) err = 1;
   }
-  if (!err && wp < need) err = 1;  // the stream ends before the last scanline the window needs
-  if (!err && flushed < need) {    // the last, partial unit (the buffer has 1 KB of slack behind `need`)
-    __syncthreads();
+  lds_store(&sm->q_tail, tail, lane);
+  lds_store(&sm->q_eos, 1u, lane);
+#ifdef HCIR_PNG_STAMPS
+  STAMP(0);
+  if (lane == 0 && diag) {
+    for (int i = 0; i < 8; ++i) diag[i] = st_acc[i];
+    diag[8] = st_n[0];
+    diag[10] = st_n[2];
+    diag[11] = st_n[3];
+  }
+#endif
+  return err;
+}
+
+__device__ __forceinline__ int copy_wave(const PngBatch& a, Smem3* sm, uint8_t* raw, uint32_t need, int lane,
+                                         uint64_t* diag) {
+  int err = 0;
+  uint32_t head = 0, wp = 0, flushed = 0;
+  STAMP_DECL;
+  for (uint32_t polls = 0;;) {
+    const uint32_t eos = lds_load(&sm->q_eos);  // read BEFORE the tail: a tail read after "no more" is the final one
+    const uint32_t tail = lds_load(&sm->q_tail);
+    const uint32_t avail = tail - head;
+    if (avail < 64 && !(eos && avail)) {
+      if (eos) break;  // drained
+      if (++polls > kPollLimit) {
+        err = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    polls = 0;
+    STAMP(0);
+    const uint32_t nsym = avail < 64 ? avail : 64;
+    const uint32_t sym = sm->symq[(head + lane) & (kQueue - 1)];
+    COUNT(1, (uint32_t)__popcll(__ballot((uint32_t)lane < nsym && ((sym >> 7) & 1))));
+    bool bad;
+    wp += resolve(sm, sym, nsym, wp, lane, &bad);
+    head += nsym;
+    lds_store(&sm->q_head, head, lane);
+    STAMP(4);
+    WAVE_SYNC();
+    flush_units(sm, raw, flushed, wp, need, lane);
+    STAMP(5);
+    if (bad) err = 1;
+    if (bad || wp >= need) break;
+  }
+  lds_store(&sm->q_stop, 1u, lane);  // whatever the reason: the decoder need not go on
+  if (!err && wp < need) err = 1;    // the stream ends before the last scanline the window needs (or the decoder failed)
+  if (!err && flushed < need) {      // the last, partial unit (the buffer has 1 KB of slack behind `need`)
+    WAVE_SYNC();
     *reinterpret_cast<u32x4*>(raw + flushed + lane * 16) =
         *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(sm->ring + ((flushed + lane * 16) & (kRing - 1)));
   }
-  if (lane == 0) a.status[img] = err ? HCIR_ERR_INVALID : HCIR_OK;
 #ifdef HCIR_PNG_STAMPS
   STAMP(0);
-  if (lane == 0 && a.diag) {
-    uint64_t* d = a.diag + img * 16;
-    for (int i = 0; i < 8; ++i) d[i] = st_acc[i];
-    for (int i = 0; i < 4; ++i) d[8 + i] = st_n[i];
-    d[12] = wall_clock64();
+  if (lane == 0 && diag) {
+    diag[13] = st_acc[0];  // waiting for symbols
+    diag[14] = st_acc[4];  // copying
+    diag[15] = st_acc[5];  // write-out
+    diag[9] = st_n[1];
   }
 #endif
+  return err;
+}
+
+__global__ __launch_bounds__(128) void png_inflate_kernel(PngBatch a) {
+  __shared__ __attribute__((aligned(16))) Smem smem;
+  Smem3* sm = (Smem3*)&smem;
+
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+  const int64_t img = blockIdx.x;
+  const hcir_png_header* hp = reinterpret_cast<const hcir_png_header*>(a.blob) + img;
+  const int32_t width = hp->width, height = hp->height, bpp = hp->bpp;
+  if (width <= 0) {
+    if (threadIdx.x == 0) a.status[img] = HCIR_OK;  // a file the stager rejected: skipped
+    return;
+  }
+  png_host::Win wn;
+  png_host::window(width, height, a.win_h, a.win_w, wn);
+  const uint32_t need = wn.y1 > 0 && wn.x1 > wn.x0 ? (uint32_t)wn.y1 * (1u + (uint32_t)width * (uint32_t)bpp) : 0u;
+  if (need == 0) {
+    if (threadIdx.x == 0) a.status[img] = HCIR_OK;
+    return;
+  }
+  if (threadIdx.x == 0) {
+    sm->q_tail = sm->q_head = sm->q_eos = sm->q_stop = 0;
+    sm->errs[0] = sm->errs[1] = 0;
+  }
+  __syncthreads();
+  uint64_t* diag = nullptr;
+#ifdef HCIR_PNG_STAMPS
+  diag = a.diag ? a.diag + img * 16 : nullptr;
+#endif
+  int err;
+  if (wave == 0)
+    err = decode_wave(a, sm, a.blob + hp->stage_offset, hp->stream_bytes, lane, diag);
+  else
+    err = copy_wave(a, sm, a.raw + (uint64_t)img * a.raw_stride, need, lane, diag);
+  if (lane == 0) sm->errs[wave] = err;
+  __syncthreads();
+  if (threadIdx.x == 0) a.status[img] = (sm->errs[0] | sm->errs[1]) ? HCIR_ERR_INVALID : HCIR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1048,7 +1139,7 @@ extern "C" int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_he
   a.raw_stride = p.raw_stride;
   a.status = status_dev ? status_dev : reinterpret_cast<int32_t*>(ws + (size_t)b * p.raw_stride);
   a.diag = reinterpret_cast<uint64_t*>(ws + (((size_t)b * p.raw_stride + (size_t)b * 4 + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)b), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)b), dim3(128), 0, st, a);
   HCIR_LAUNCH_CHECK();
   const size_t lds = (size_t)p.max_x1 * 4;
   if (p.any[1]) hipLaunchKernelGGL(png_unfilter_kernel<1>, dim3((unsigned)b), dim3(64), lds, st, a);

@@ -22,7 +22,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 STAT_NAMES = ("stored_blocks", "fixed_blocks", "dynamic_blocks", "literals", "matches", "match_bytes", "overlapping",
-              "dist_le_4k", "dist_le_8k", "dist_le_16k", "dist_gt_16k", "long_codes", "consumed_bytes")
+              "dist_le_4k", "dist_le_8k", "dist_le_16k", "dist_gt_16k", "long_codes", "consumed_bytes", "codes_gt_11",
+              "codes_gt_12")
 
 
 class Corrupt(ValueError):

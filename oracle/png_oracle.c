@@ -99,7 +99,7 @@ static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
 
 /* stats[] (optional, 16 x uint64): 0 stored blocks, 1 fixed, 2 dynamic, 3 literals, 4 matches, 5 match bytes,
  * 6 matches with dist < len, 7 dist <= 4096, 8 dist <= 8192, 9 dist <= 16384, 10 dist > 16384, 11 long litlen
- * codes (> 10 bits), 12 consumed input bytes at the point of return. */
+ * codes (> 10 bits), 12 consumed input bytes at the point of return, 13 / 14 codes > 11 / > 12 bits. */
 static int codes(bits_t* s, uint8_t* out, size_t cap, size_t* pos, const huff_t* lc, const huff_t* dc, uint64_t* st) {
   for (;;) {
     size_t b0 = s->byte * 8 + s->bit;
@@ -107,6 +107,8 @@ static int codes(bits_t* s, uint8_t* out, size_t cap, size_t* pos, const huff_t*
     if (s->over) return E_CORRUPT;
     if (sym < 0) return E_CORRUPT;
     if (st && (s->byte * 8 + s->bit) - b0 > 10) st[11]++;
+    if (st && (s->byte * 8 + s->bit) - b0 > 11) st[13]++;
+    if (st && (s->byte * 8 + s->bit) - b0 > 12) st[14]++;
     if (sym < 256) {
       if (*pos >= cap) return TRUNCATED_AT_CAP;
       out[(*pos)++] = (uint8_t)sym;

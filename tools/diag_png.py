@@ -36,7 +36,7 @@ def main():
     base = (-ws.data_ptr()) % 256
     off = base + ((batch * stride + batch * 4 + 255) & ~255)
     g = ws[off:off + batch * 128].cpu().numpy().view(np.uint64).reshape(batch, 16)
-    names = ["other", "header", "lookup", "walk", "resolve", "flush", "glue", "slow"]
+    names = ["other", "header", "lookup", "walk", "-", "-", "glue", "slow"]
     for i in range(min(batch, 8)):
         r = g[i].astype(np.float64)
         tot = r[:8].sum()
@@ -44,7 +44,9 @@ def main():
         print(f"img {i}: file {len(fl[i])} B, {nsym:.0f} symbols, {nmatch:.0f} matches, {npass:.0f} passes, "
               f"{tot / 1e6:.1f} Mcycles = {tot / max(nsym, 1):.0f} cyc/symbol")
         print("   " + "  ".join(f"{n} {r[k] / tot * 100:.1f}% ({r[k] / max(nsym, 1):.0f}/sym)" for k, n in enumerate(names)))
-        print(f"   lookup {r[2] / max(npass, 1):.0f} cyc/pass, resolve {r[4] / max(nmatch, 1):.0f} cyc/match, "
+        print(f"   copier: waiting {r[13] / max(nsym, 1):.0f}/sym, copying {r[14] / max(nsym, 1):.0f}/sym "
+              f"({r[14] / max(nmatch, 1):.0f} cyc/match), write-out {r[15] / max(nsym, 1):.0f}/sym")
+        print(f"   lookup {r[2] / max(npass, 1):.0f} cyc/pass, "
               f"{nslow:.0f} serially decoded symbols at {r[7] / max(nslow, 1):.0f} cyc, glue {r[6] / max(npass, 1):.0f} cyc/pass")
 
 

@@ -428,9 +428,12 @@ __device__ __forceinline__ void lookup_span(const Smem3* sm, const uint32_t* lo,
   }
 }
 
+#ifndef HCIR_PNG_SLOW_INLINE
+#define HCIR_PNG_SLOW_INLINE __noinline__
+#endif
 // the same for ONE position, serially, with the long codes searched (wave-uniform).  The packed symbol; for the
 // end of the block kStop | S_EOB | its code length << 9; ~0: no valid symbol starts here.
-__device__ __noinline__ uint32_t lookup_slow(uint32_t lo, uint32_t hi, Smem3* sm, int lane) {
+__device__ HCIR_PNG_SLOW_INLINE uint32_t lookup_slow(uint32_t lo, uint32_t hi, Smem3* sm, int lane) {
   lo = U(lo);
   hi = U(hi);
   uint32_t e1 = U(sm->lit_tab[lo & ((1 << kLitRoot) - 1)]);

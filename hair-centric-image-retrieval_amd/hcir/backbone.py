@@ -111,7 +111,7 @@ class MAE(nn.Module):
 
     def extract_features(self, images):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP ViT path is forward-only this round: use torch.no_grad()")
+            raise NotImplementedError("this model family is inference-only on the HIP path (the differentiable ViT is SHAM2 / ViTWrapper.forward_cls, hcir.vit_train): wrap the call in torch.no_grad()")
         eng = self._cache.get(list(self.backbone.vit.parameters()), self._spec, images.device)
         tok = eng.forward_tokens(images, cls_only_last=True)
         return eng.cls_embedding(tok, final_norm=True, l2_normalize=False)

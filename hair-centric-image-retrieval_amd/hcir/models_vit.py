@@ -168,7 +168,7 @@ class VisionTransformer(nn.Module):
 
     def forward_features(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP ViT path is forward-only this round: use torch.no_grad()")
+            raise NotImplementedError("this model family is inference-only on the HIP path (the differentiable ViT is SHAM2 / ViTWrapper.forward_cls, hcir.vit_train): wrap the call in torch.no_grad()")
         return self.engine(x.device).forward_tokens(x).to(torch.float32, copy=True)  # own fp32 copy, as the reference returns
 
 

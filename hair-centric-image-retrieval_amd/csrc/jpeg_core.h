@@ -365,35 +365,39 @@ JHD int32_t jpeg_window_slot(const hcir_jpeg_header& h, const JWin& w, uint32_t 
 }
 
 // ---- jidctint.c: jpeg_idct_islow ------------------------------------------------------------------------
-JHD int32_t jpeg_descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+JHD int32_t jpeg_descale(uint32_t x, int n) { return (int32_t)(x + (1u << (n - 1))) >> n; }
 
-// one 8-point pass; in/out strides let the same code run down columns (pass 1) and along rows (pass 2)
+// one 8-point pass; in/out strides let the same code run down columns (pass 1) and along rows (pass 2).
+// All products and sums in uint32_t (two's-complement wrap, what the device's 32-bit ALU does anyway): with 16-bit
+// quantisation tables or corrupt coefficients the signed forms overflow, which is undefined behaviour in the
+// host-compiled emulation (tests/jpeg_emul.cpp) - found by a UBSan fuzz of that file.
 JHD void jpeg_idct8(const int32_t* in, int istride, int32_t* out, int ostride, int shift) {
-  constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
-                    F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-  int32_t z2 = in[2 * istride], z3 = in[6 * istride];
-  int32_t z1 = (z2 + z3) * F0_541;
-  const int32_t tmp2 = z1 + z3 * (-F1_847);
-  const int32_t tmp3 = z1 + z2 * F0_765;
-  z2 = in[0];
-  z3 = in[4 * istride];
-  const int32_t tmp0 = (int32_t)((uint32_t)(z2 + z3) << 13);
-  const int32_t tmp1 = (int32_t)((uint32_t)(z2 - z3) << 13);
-  const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-  int32_t t0 = in[7 * istride], t1 = in[5 * istride], t2 = in[3 * istride], t3 = in[1 * istride];
+  typedef uint32_t U;
+  constexpr U F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+              F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+  U z2 = (U)in[2 * istride], z3 = (U)in[6 * istride];
+  U z1 = (z2 + z3) * F0_541;
+  const U tmp2 = z1 - z3 * F1_847;
+  const U tmp3 = z1 + z2 * F0_765;
+  z2 = (U)in[0];
+  z3 = (U)in[4 * istride];
+  const U tmp0 = (z2 + z3) << 13;
+  const U tmp1 = (z2 - z3) << 13;
+  const U tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  U t0 = (U)in[7 * istride], t1 = (U)in[5 * istride], t2 = (U)in[3 * istride], t3 = (U)in[1 * istride];
   z1 = t0 + t3;
   z2 = t1 + t2;
   z3 = t0 + t2;
-  int32_t z4 = t1 + t3;
-  const int32_t z5 = (z3 + z4) * F1_175;
+  U z4 = t1 + t3;
+  const U z5 = (z3 + z4) * F1_175;
   t0 *= F0_298;
   t1 *= F2_053;
   t2 *= F3_072;
   t3 *= F1_501;
-  z1 *= -F0_899;
-  z2 *= -F2_562;
-  z3 = z3 * (-F1_961) + z5;
-  z4 = z4 * (-F0_390) + z5;
+  z1 = 0u - z1 * F0_899;
+  z2 = 0u - z2 * F2_562;
+  z3 = z5 - z3 * F1_961;
+  z4 = z5 - z4 * F0_390;
   t0 += z1 + z3;
   t1 += z2 + z4;
   t2 += z2 + z3;

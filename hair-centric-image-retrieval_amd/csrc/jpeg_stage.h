@@ -43,6 +43,9 @@ inline int derive_table(int is_ac, const uint8_t bits[16], const uint8_t* vals, 
       size[p++] = (uint8_t)l;
     }
   if (p != nvals) return HCIR_ERR_INVALID;
+  if (!is_ac)
+    for (int i = 0; i < nvals; ++i)
+      if (vals[i] > 15) return HCIR_ERR_INVALID;  // libjpeg: JERR_BAD_HUFF_TABLE (a DC category above 15)
   uint32_t code = 0;
   int si = p ? size[0] : 0, k = 0;
   while (k < p) {
@@ -99,6 +102,8 @@ inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false}, have_sof = false;
   int comp_id[3] = {0, 0, 0}, comp_tq[3] = {0, 0, 0};
+  bool saw_jfif = false, saw_adobe = false;
+  int adobe_transform = 0;
   size_t i = 2;
   for (;;) {
     if (i + 4 > n || f[i] != 0xFF) return HCIR_ERR_INVALID;
@@ -111,7 +116,12 @@ inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
     if (len < 2 || i + len > n) return HCIR_ERR_INVALID;
     const uint8_t* s = f + i + 2;
     const size_t sl = len - 2;
-    if (m == 0xDB) {
+    if (m == 0xE0 && sl >= 14 && !memcmp(s, "JFIF\0", 5)) {
+      saw_jfif = true;
+    } else if (m == 0xEE && sl >= 12 && !memcmp(s, "Adobe", 5)) {
+      saw_adobe = true;
+      adobe_transform = s[11];
+    } else if (m == 0xDB) {
       size_t j = 0;
       while (j < sl) {
         const int pq = s[j] >> 4, tq = s[j] & 15;
@@ -178,6 +188,13 @@ inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
       break;
     }
     i += len;
+  }
+  // colour space of a three-component file as libjpeg decides it (jdapimin.c default_decompress_parms): JFIF -> YCbCr;
+  // else Adobe transform 0 -> RGB; else component ids 'R','G','B' -> RGB.  RGB files are not converted by libjpeg:
+  // the device path (which always converts) leaves them to the host decoder
+  if (h->ncomp == 3 && !saw_jfif) {
+    if (saw_adobe ? adobe_transform == 0 : (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B'))
+      return HCIR_ERR_UNSUPPORTED;
   }
   // frame geometry
   if (h->ncomp == 1) {

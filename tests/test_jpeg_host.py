@@ -194,3 +194,27 @@ def test_emulated_device_path_matches_live_pillow(emul):
                                                           err_msg=f"{h}x{w} ss{ss} ri{ri} grey{grey} win{wh}x{ww} T{threads}")
                             n += 1
     assert n > 500
+
+
+def test_stage_leaves_rgb_jpegs_to_the_host(hcir_built):
+    """libjpeg's colour-space rule (jdapimin.c default_decompress_parms): a three-component file without a JFIF marker
+    whose Adobe marker says transform 0 (or whose component ids are 'R','G','B') is RGB and is NOT converted.  The
+    device path always converts, so the stager hands such files to the host decoder; and a DC Huffman
+    table with a category above 15 is a bad table, as in jdhuff.c."""
+    from hcir import jpeg
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=90, keep_rgb=True)   # Adobe APP14, transform 0, no JFIF
+    assert b"Adobe" in b.getvalue() and b"JFIF" not in b.getvalue()
+    assert jpeg.stage_batch([b.getvalue()], pin=False).status.tolist() == [-2]
+    b2 = io.BytesIO()
+    Image.fromarray(a).save(b2, "JPEG", quality=90)
+    good = b2.getvalue()
+    assert jpeg.stage_batch([good], pin=False).status.tolist() == [0]
+    # corrupt the first DC table's first symbol to 16
+    i = good.index(b"\xff\xc4")
+    assert good[i + 4] >> 4 == 0  # a DC table
+    bad = bytearray(good)
+    bad[i + 5 + 16] = 16
+    assert jpeg.stage_batch([bytes(bad)], pin=False).status.tolist() == [-1]

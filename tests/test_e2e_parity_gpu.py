@@ -59,3 +59,32 @@ def test_e2e_mismatches_are_near_ties(hcir_built, resid):
         extra = set(i_e[qi]) - set(ref_idx[qi])
         for j in extra:
             assert s64[qi, ref_idx[qi, -1]] - s64[qi, j] <= bound[qi, 0]
+
+    # ---- the tight statement: every pair of gallery rows whose ORDER differs between the two rankings
+    # is separated, in the oracle's scores, by no more than twice the amount the embedding difference moves THAT pair,
+    # |<e_hip - e_ref, g_i - g_j>|, plus the fp32 rounding of two 768-term dot products (4e-6) - not the Cauchy-Schwarz
+    # envelope of the norm of the difference.  Pairs are taken from the union of the two top-k lists; a row outside a
+    # list ranks behind every row inside it.
+    de = (e_hip.cpu().double() - emb.double()).numpy()
+    g64 = g.double().numpy()
+    checked = flipped = 0
+    worst = 0.0
+    for qi in range(n):
+        pos_h = {int(j): p for p, j in enumerate(i_e[qi])}
+        pos_r = {int(j): p for p, j in enumerate(ref_idx[qi])}
+        union = sorted(set(pos_h) | set(pos_r))
+        for ai in range(len(union)):
+            for bi in range(ai + 1, len(union)):
+                a, b = union[ai], union[bi]
+                if (a not in pos_h and b not in pos_h) or (a not in pos_r and b not in pos_r):
+                    continue  # both outside one of the lists: their order there is unknown
+                before_h = pos_h.get(a, k) < pos_h.get(b, k)
+                before_r = pos_r.get(a, k) < pos_r.get(b, k)
+                checked += 1
+                if before_h != before_r:
+                    flipped += 1
+                    gap_ab = abs(s64[qi, a] - s64[qi, b])
+                    moved = abs(float(de[qi] @ (g64[a] - g64[b])))
+                    worst = max(worst, gap_ab / (2.0 * moved + 4e-6))
+                    assert gap_ab <= 2.0 * moved + 4e-6, (qi, a, b, gap_ab, moved)
+    print(f"resid {resid}: {flipped} of {checked} pairs change order; worst gap / (2 x pair perturbation + 4e-6) = {worst:.2f}")

@@ -225,3 +225,66 @@ def test_loader_routes_png_and_jpeg_to_the_device(tmp_path, streams, hcir_built)
             assert torch.equal(rl, el)
             assert any(k == "png" for k, _, _ in eb.parts)
             assert torch.equal(eb.decode("cuda").cpu(), rw)
+
+
+def test_mutated_streams_never_fault_and_agree_with_pillow(streams, hcir_built):
+    """384 files whose zlib streams carry random byte / bit damage (chunk CRCs re-made, so only the decoder can notice):
+    the launch must come back (every loop of the kernels consumes input or leaves; the two wavefronts' polls are
+    bounded), and whenever Pillow decodes a damaged file the device must report it sound and give the same window —
+    damage behind the last scanline the window needs is invisible to both.  Where the device flags a file, Pillow must
+    have rejected it too."""
+    import warnings
+    from hcir import png
+    names, files, wins = streams
+    rng = np.random.default_rng(77)
+    bases = [files[names.index(n)] for n in ("filter4_rgb", "mixed_blocks", "grey_l1", "palette", "mixed_filters_rgba_l9",
+                                             "fixed_blocks")]
+    muts = []
+    for k in range(384):
+        f = bases[k % len(bases)]
+        i = f.index(b"IDAT")
+        n = struct.unpack(">I", f[i - 4:i])[0]
+        z = bytearray(f[i + 4:i + 4 + n])
+        kind = k % 4
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(2, len(z)))
+            if kind == 0:
+                z[at] ^= 1 << int(rng.integers(0, 8))          # one bit
+            elif kind == 1:
+                z[at] = int(rng.integers(0, 256))               # one byte
+            elif kind == 2:
+                z[at:at + 8] = bytes(rng.integers(0, 256, 8).astype(np.uint8))[:len(z) - at]   # a burst
+            else:
+                del z[at:at + int(rng.integers(1, 40))]         # bytes lost: everything behind shifts
+        muts.append(f[:i - 4] + chunk(b"IDAT", bytes(z)) + chunk(b"IEND", b""))
+    staged = png.stage_batch(muts)
+    assert staged.rejected == []
+    dev = staged.to("cuda")
+    st = torch.zeros(len(muts), dtype=torch.int32, device="cuda")
+    out = torch.empty((len(muts), 224, 224, 3), dtype=torch.uint8, device="cuda")
+    L = hcir_built
+    ws = torch.empty(L.hcir_png_workspace_bytes(staged._host_headers.data_ptr(), staged.b, 224, 224), dtype=torch.uint8,
+                     device="cuda")
+    assert L.hcir_png_decode_window_u8(dev.blob.data_ptr(), staged._host_headers.data_ptr(), staged.b, 224, 224,
+                                       out.data_ptr(), st.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    out = out.cpu().numpy()
+    sound = flagged = 0
+    for k, f in enumerate(muts):
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = _window(_pil(f), 224, 224)
+        except Exception:  # noqa: BLE001 - Pillow rejects the file (zlib error, truncated data, bad Adler-32 ...)
+            ref = None
+        if ref is not None:
+            sound += 1
+            assert st[k] == 0, f"mutant {k}: Pillow decodes it, the device flags it"
+            np.testing.assert_array_equal(out[k], ref, err_msg=f"mutant {k}")
+        if st[k] != 0:
+            flagged += 1
+            assert ref is None
+    assert flagged > 100 and st.min() >= -1
+    print(f"{flagged} of {len(muts)} mutants flagged by the device, {sound} decoded by Pillow")

@@ -149,3 +149,33 @@ def test_stage_batch_and_workspace(streams, hcir_built):
     assert L.hcir_png_workspace_bytes(st._host_headers.data_ptr(), st.b, 0, 224) == 0
     with pytest.raises(png.HcirError):
         png.decode_windows(st)  # a host blob: the decoder is device-only, no CPU fallback
+
+
+def test_stager_fuzz_under_sanitizers(streams):
+    """The host stager (png_stage.h) against 20 000 mutated / truncated files under AddressSanitizer + UBSan."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "libpng_stage_fuzz.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", os.path.join(root, "tests", "png_stage_fuzz.cpp"), "-o", exe])
+    names, files, _, _ = streams
+    driver = (
+        "import ctypes, sys, numpy as np\n"
+        "L = ctypes.CDLL(sys.argv[1])\n"
+        "z = np.load(sys.argv[2])\n"
+        "tot = 0\n"
+        "for i in (4, 9, 12, 13, 16, 20, 23):\n"
+        "    f = z['data'][z['offsets'][i]:z['offsets'][i + 1]].copy()\n"
+        "    acc = ctypes.c_int64(0)\n"
+        "    rc = L.png_stage_fuzz(f.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(f.size), 3000, ctypes.byref(acc))\n"
+        "    assert rc == 0, rc\n"
+        "    tot += acc.value\n"
+        "print('accepted', tot)\n")
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, "-c", driver, exe, os.path.join(root, "tests", "golden", "png_streams.npz")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "accepted" in r.stdout

@@ -51,6 +51,7 @@ def parse():
                     help="storage type of the ViT residual stream (fp16: half the LayerNorm / residual-epilogue "
                          "traffic, 1-cos vs the fp32 oracle 4e-7; fp32: 1e-7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step in flight (no second HIP stream) at N = 1")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip batch_sweep / vendor yardstick / PCIe-inclusive side measurements (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="query images in the CPU baseline sample")
@@ -516,17 +517,33 @@ def main():
         pending[0] = None
         return out
 
-    for _ in range(args.warmup):
-        step()
-    drain()
+    # One rank: two steps in flight on two HIP streams (hcir.pipeline.StreamPipeline: step i + 1's embed fills the
+    # partial tile rounds and the dependent-dispatch gaps of step i; every step is finished - certified, merged -
+    # before the clock stops).  Several ranks keep ONE stream: the two all-gathers of a step are collectives, and
+    # collectives issued from two streams may run in another order on another rank.
+    in_flight = 2 if (world == 1 and gdtype == torch.float32 and not args.no_pipeline) else 1
+    pipe = None
+    if in_flight > 1:
+        from hcir.pipeline import StreamPipeline
+        pipe = StreamPipeline(vit, gallery, args.topk, depth=in_flight, device=dev)
+
+    def run_steps(count):
+        if pipe is None:
+            for _ in range(count):
+                step()
+            drain()
+        else:
+            for _ in range(count):
+                pipe.submit(x)
+            pipe.drain()
+
+    run_steps(max(args.warmup, in_flight))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -819,6 +836,7 @@ def main():
                        "query_batch_per_gpu": args.batch, "global_query_batch": nq_all,
                        "gallery_rows": args.gallery, "gallery_dtype": args.gallery_dtype, "topk": args.topk,
                        "sim_mode": args.sim_mode, "residual_stream": args.resid,
+                       "steps_in_flight": in_flight,
                        "parallelism": f"gallery-shard{world}+query-dp{world}"},
             # dominant kernel by time: the fp16 MFMA GEMM (4 per layer x 12 layers per step)
             "roofline": {"kernel": "gemm_f16_big_kernel (qkv, proj, fc1, fc2)", "bound": "mfma",

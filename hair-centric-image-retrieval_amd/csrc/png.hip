@@ -922,9 +922,15 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+constexpr int kRawPitch = 272;  // bytes of LDS per scanline window: 256 + 16 (a multiple of 16 that is not one of 256)
+
 template <int BPP>
 __global__ __launch_bounds__(64) void png_unfilter_kernel(PngBatch a) {
-  extern __shared__ uint32_t lastrow[];  // packed pixels of the previous band's last row, [x1]
+  // [64 x kRawPitch] a 256-byte ring of every lane's scanline (indexed by the byte's offset in the image's buffer
+  // & 255), then [x1] the packed pixels of the previous band's last row, then 64 dump words
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+  uint8_t* ring = reinterpret_cast<uint8_t*>(dyn);
+  uint32_t* lastrow = dyn + 64 * kRawPitch / 4;
   __shared__ uint8_t pal[768];
   __shared__ int bad_filter;
   const int lane = (int)threadIdx.x;
@@ -949,71 +955,79 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(PngBatch a) {
   if (lane == 0) bad_filter = 0;
   __syncthreads();
   const uint32_t stride = 1u + (uint32_t)width * BPP;
-  const uint8_t* raw = a.raw + (uint64_t)img * a.raw_stride;
+  const uint8_t* raw = a.raw + (uint64_t)img * a.raw_stride;  // 256-B aligned: buffer offsets keep their alignment
+  uint8_t* myring = ring + lane * kRawPitch;
 
   for (int32_t band = 0; band * 64 < rows; ++band) {
     const int32_t r = band * 64 + lane;
     const bool live = r < rows;
-    const uint8_t* row = raw + (uint64_t)(live ? r : 0) * stride;
-    const uint32_t ft = live ? row[0] : 0u;
+    const uint32_t rowoff = (uint32_t)(live ? r : 0) * stride;  // offset of the row's filter byte
+    const uint32_t ft = live ? raw[rowoff] : 0u;
     if (ft > 4) bad_filter = 1;
+    const int32_t m_sub = -(int32_t)(ft == 1), m_up = -(int32_t)(ft == 2), m_avg = -(int32_t)(ft == 3),
+                  m_paeth = -(int32_t)(ft == 4);
+    const uint32_t data0 = rowoff + 1;
+    // The lane's scanline streams through its ring in aligned 16-B pieces, 64-112 bytes ahead of the pixel it is at
+    // (one coalescible 16-B load per four steps instead of twelve byte loads whose 64 addresses each are 64 cache
+    // lines: the address unit was what this kernel waited for).  A piece is stored to LDS one group after its load.
+    uint32_t fp = data0 & ~15u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      *reinterpret_cast<u32x4*>(myring + (fp & 255)) = *reinterpret_cast<const u32x4*>(raw + fp);
+      fp += 16;
+    }
+    u32x4 pend = {0, 0, 0, 0};
+    uint32_t pend_at = 0;
+    bool pending = false;
     uint32_t cur = 0, prv = 0;
-    uint32_t nxt[4];  // raw pixels of the next four steps, loaded four steps ahead
-    auto load4 = [&](int32_t t0, uint32_t* dst) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int32_t x = t0 + s - lane;
-        uint32_t v = 0;
-        if (live && x >= 0 && x < xe) {
-          const uint8_t* p = row + 1 + (uint32_t)x * BPP;
-#pragma unroll
-          for (int c = 0; c < BPP; ++c) v |= (uint32_t)p[c] << (8 * c);
-        }
-        dst[s] = v;
-      }
-    };
-    load4(0, nxt);
     const int32_t steps = xe + 63;
     for (int32_t t0 = 0; t0 < steps; t0 += 4) {
-      uint32_t now[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) now[s] = nxt[s];
-      if (t0 + 4 < steps) load4(t0 + 4, nxt);
+      if (pending) *reinterpret_cast<u32x4*>(myring + pend_at) = pend;
+      pending = live && (int32_t)fp < (int32_t)data0 + (t0 + 8 - lane) * BPP + 64;
+      if (pending) {
+        pend = *reinterpret_cast<const u32x4*>(raw + fp);
+        pend_at = fp & 255;
+        fp += 16;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int32_t x = t0 + s - lane;
         const bool act = live && x >= 0 && x < xe;
+        // No EXEC toggling except around the output store: every lane reads the previous band's last row (only lane
+        // 0 keeps it), every lane writes (lane 63 to the row buffer, the others to a dump word of their own).
+        const int32_t xc = x < 0 ? 0 : (x >= xe ? xe - 1 : x);
+        const uint32_t lr_up = lastrow[xc], lr_ul = lastrow[xc > 0 ? xc - 1 : 0];
         uint32_t up = wave_shr1(cur), ul = wave_shr1(prv);
-        if (lane == 0) {
-          up = (band > 0 && act) ? lastrow[x] : 0u;
-          ul = (band > 0 && act && x > 0) ? lastrow[x - 1] : 0u;
-        }
-        if (x == 0) ul = 0;
+        up = lane == 0 ? (band > 0 ? lr_up : 0u) : up;
+        ul = lane == 0 ? (band > 0 ? lr_ul : 0u) : ul;
+        ul = x <= 0 ? 0u : ul;
         const uint32_t left = x > 0 ? cur : 0u;
+        const uint32_t at = data0 + (uint32_t)x * BPP;
         uint32_t res = 0;
 #pragma unroll
         for (int c = 0; c < BPP; ++c) {
           const int32_t av = (int32_t)((left >> (8 * c)) & 255), bv = (int32_t)((up >> (8 * c)) & 255),
-                        cv = (int32_t)((ul >> (8 * c)) & 255), xv = (int32_t)((now[s] >> (8 * c)) & 255);
+                        cv = (int32_t)((ul >> (8 * c)) & 255), xv = (int32_t)myring[(at + c) & 255];
+          // all five predictors, chosen by bit masks (hipcc turns the ternary chains into EXEC-masked branches:
+          // fifteen skip branches per pixel were two thirds of this kernel's time)
           const int32_t pa = abs(bv - cv), pb = abs(av - cv), pc = abs(av + bv - 2 * cv);
-          const int32_t paeth = (pa <= pb && pa <= pc) ? av : (pb <= pc ? bv : cv);
-          const int32_t pred = ft == 0 ? 0 : ft == 1 ? av : ft == 2 ? bv : ft == 3 ? ((av + bv) >> 1) : paeth;
+          const int32_t ca = -(int32_t)((pa <= pb) & (pa <= pc)), cb = -(int32_t)(pb <= pc);
+          const int32_t paeth = (av & ca) | (~ca & ((bv & cb) | (cv & ~cb)));
+          const int32_t pred = (av & m_sub) | (bv & m_up) | (((av + bv) >> 1) & m_avg) | (paeth & m_paeth);
           res |= (uint32_t)((xv + pred) & 255) << (8 * c);
         }
-        if (act) {
-          prv = cur;
-          cur = res;
-          if (lane == 63) lastrow[x] = res;
-          if (r >= wn.y0 && x >= wn.x0) {
-            uint8_t* o = out + ((uint64_t)(r - wn.y0 + wn.oy) * (uint32_t)a.win_w + (uint32_t)(x - wn.x0 + wn.ox)) * 3u;
-            if (BPP >= 3) {
-              o[0] = (uint8_t)res, o[1] = (uint8_t)(res >> 8), o[2] = (uint8_t)(res >> 16);
-            } else if (ctype == 3) {
-              const uint32_t i = (res & 255) * 3;
-              o[0] = pal[i], o[1] = pal[i + 1], o[2] = pal[i + 2];
-            } else {
-              o[0] = o[1] = o[2] = (uint8_t)res;
-            }
+        prv = act ? cur : prv;
+        cur = act ? res : cur;
+        lastrow[(lane == 63 && act) ? x : xe + lane] = res;  // [xe, xe + 64): the dump words
+        if (act && r >= wn.y0 && x >= wn.x0) {
+          uint8_t* o = out + ((uint64_t)(r - wn.y0 + wn.oy) * (uint32_t)a.win_w + (uint32_t)(x - wn.x0 + wn.ox)) * 3u;
+          if (BPP >= 3) {
+            o[0] = (uint8_t)res, o[1] = (uint8_t)(res >> 8), o[2] = (uint8_t)(res >> 16);
+          } else if (ctype == 3) {
+            const uint32_t i = (res & 255) * 3;
+            o[0] = pal[i], o[1] = pal[i + 1], o[2] = pal[i + 2];
+          } else {
+            o[0] = o[1] = o[2] = (uint8_t)res;
           }
         }
       }
@@ -1144,7 +1158,7 @@ extern "C" int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_he
   a.diag = reinterpret_cast<uint64_t*>(ws + (((size_t)b * p.raw_stride + (size_t)b * 4 + 255) & ~(size_t)255));
   hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)b), dim3(128), 0, st, a);
   HCIR_LAUNCH_CHECK();
-  const size_t lds = (size_t)p.max_x1 * 4;
+  const size_t lds = (size_t)64 * kRawPitch + ((size_t)p.max_x1 + 64) * 4;  // + the 64 dump words behind the row
   if (p.any[1]) hipLaunchKernelGGL(png_unfilter_kernel<1>, dim3((unsigned)b), dim3(64), lds, st, a);
   if (p.any[2]) hipLaunchKernelGGL(png_unfilter_kernel<2>, dim3((unsigned)b), dim3(64), lds, st, a);
   if (p.any[3]) hipLaunchKernelGGL(png_unfilter_kernel<3>, dim3((unsigned)b), dim3(64), lds, st, a);

@@ -461,6 +461,7 @@ __device__ HCIR_PNG_SLOW_INLINE uint32_t lookup_slow(uint32_t lo, uint32_t hi, S
 // Written out: six scalar instructions per symbol and one conditional branch.  Measured on gfx950
 // (tools/ubench/walk_latency.hip): v_readlane -> SALU -> v_readlane round trip 29 cycles, a dependent SALU
 // instruction 4, a conditional branch 16 NOT taken and 20 taken - the branch count is what this loop is built around.
+#ifndef HCIR_PNG_WALK_BRANCHFREE   // default: a conditional branch behind every step (16 cycles even when not taken)
 #define HCIR_WALK_STEP(C, M, X)          \
   "v_readlane_b32 %[e], %[" C "], %[p]\n\t" \
   "s_bitset1_b64 %[" M "], %[p]\n\t"        \
@@ -468,9 +469,29 @@ __device__ HCIR_PNG_SLOW_INLINE uint32_t lookup_slow(uint32_t lo, uint32_t hi, S
   "s_add_u32 %[p], %[p], %[t]\n\t"          \
   "s_cmp_gt_u32 %[p], 63\n\t"               \
   "s_cbranch_scc1 " X "_%=\n\t"
+#define HCIR_WALK_STEPS(C, M, X) HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X)
+#else
+// EXPERIMENT (build flag), measured and rejected: a branch-free step - once the chain has left the window (p >= 64) a
+// step changes nothing (entry, mark and advance are selected away), four steps back to back, ONE branch behind them:
+// nine scalar instructions per symbol.  Walk 69 -> 79 and 83 -> 105 cycles per symbol, the 880-image launch 45.0 ->
+// 52.6 ms (same box, interleaved): the selects lengthen the dependent chain by more than the branch costs.
+#define HCIR_WALK_STEP(C, M, X)              \
+  "v_readlane_b32 %[e2], %[" C "], %[p]\n\t" \
+  "s_and_b32 %[t], %[e2], 127\n\t"           \
+  "s_lshl_b64 %[b], 1, %[p]\n\t"             \
+  "s_cmp_lt_u32 %[p], 64\n\t"                \
+  "s_cselect_b32 %[e], %[e2], %[e]\n\t"      \
+  "s_cselect_b32 %[t], %[t], 0\n\t"          \
+  "s_cselect_b64 %[b], %[b], 0\n\t"          \
+  "s_or_b64 %[" M "], %[" M "], %[b]\n\t"    \
+  "s_add_u32 %[p], %[p], %[t]\n\t"
+#define HCIR_WALK_STEPS(C, M, X)                                                                     \
+  HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X) HCIR_WALK_STEP(C, M, X) \
+  "s_cmp_gt_u32 %[p], 63\n\t"                                                                     \
+  "s_cbranch_scc1 " X "_%=\n\t"
+#endif
 #define HCIR_WALK_WINDOW(N, C, M, NEXT)                                                                    \
-  ".Lw" N "_%=:\n\t" HCIR_WALK_STEP(C, M, ".Lx" N) HCIR_WALK_STEP(C, M, ".Lx" N) HCIR_WALK_STEP(C, M, ".Lx" N) \
-      HCIR_WALK_STEP(C, M, ".Lx" N) "s_branch .Lw" N "_%=\n"                                               \
+  ".Lw" N "_%=:\n\t" HCIR_WALK_STEPS(C, M, ".Lx" N) "s_branch .Lw" N "_%=\n"                             \
   ".Lx" N "_%=:\n\t"                                                                                       \
   "s_sub_u32 %[p], %[p], 64\n\t"                                                                           \
   "s_bitcmp1_b32 %[e], 6\n\t"                                                                              \
@@ -480,7 +501,8 @@ __device__ HCIR_PNG_SLOW_INLINE uint32_t lookup_slow(uint32_t lo, uint32_t hi, S
   "s_branch .Lend_%=\n"
 __device__ __forceinline__ void walk4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& w, uint32_t& p,
                                       uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3, uint32_t& e) {
-  uint32_t t;
+  uint32_t t, e2;
+  uint64_t b;
   asm volatile(
       "s_mov_b64 %[m0], 0\n\ts_mov_b64 %[m1], 0\n\ts_mov_b64 %[m2], 0\n\ts_mov_b64 %[m3], 0\n\t"
       "s_nop 3\n\t"  // p may come from a VALU-written SGPR: four wait states before it selects a lane
@@ -493,7 +515,7 @@ __device__ __forceinline__ void walk4(uint32_t c0, uint32_t c1, uint32_t c2, uin
       "s_mov_b32 %[w], 4\n"
       ".Lend_%=:\n\t"
       : [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [p] "+s"(p), [w] "+s"(w), [e] "=&s"(e),
-        [t] "=&s"(t)
+        [t] "=&s"(t), [e2] "=&s"(e2), [b] "=&s"(b)
       : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3)
       : "scc");
 }

@@ -4,8 +4,8 @@
 // src/models/hair_encoder.py:108,169 (PIL), for the format every hair-region crop it lists is stored in
 // (HairPretraining/data/data_train.csv: *_hair.png; assets/hair_region_only/*.png).
 //
-// Two kernels; per image the first runs two 64-lane wavefronts (a decoder and a copier), the second one (a batch is
-// hundreds of images: a wave or two per SIMD):
+// Two kernels; per image the first runs three 64-lane wavefronts (lookup, decoder, copier), the second one (a batch is
+// hundreds of images: a few waves per SIMD):
 //
 //  png_inflate_kernel   zlib/deflate (RFC 1950/1951) up to the last scanline the window needs.
 //    * The compressed words sit in two VGPRs (lane i = word base+i, base+64+i), fetched 256 B at a time; the
@@ -35,7 +35,9 @@ namespace {
 constexpr int kRing = 32768;  // deflate's maximum distance: the ring never needs to be larger (the reads of a copy
                               // come before its writes; literals that could alias a far source are written in order)
 constexpr int kLitRoot = 10, kDistRoot = 8, kClRoot = 7;
-constexpr uint32_t kQueue = 256;  // symbol queue entries (a ring) between the decoding and the copying wavefront
+constexpr uint32_t kQueue = 128;  // symbol queue entries (a ring) between the decoding and the copying wavefront
+constexpr uint32_t kBatchMin = 32;  // the copier takes a batch as soon as this many symbols wait (at most 64 at a time):
+                                   // the decoder can therefore always count on kQueue - kBatchMin free slots
 constexpr uint32_t K_INVALID = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_DIST = 4, K_LONG = 5, K_CL = 6;
 enum { T_CL = 0, T_LIT = 1, T_DIST = 2 };
 // A decoded symbol, packed: bits 0-6 the walk's step = stream bits it takes (code + extra bits; a match: length AND
@@ -98,6 +100,9 @@ struct Smem {
   uint8_t lens[320 + 12];
   uint8_t cl_lens[20];
   uint32_t symq[kQueue + 1];      // decoded symbols on their way to the copying wavefront (a ring) + a dump slot
+  uint32_t ent_buf[kSpan][64];    // the looked-up symbols of one pass, from the lookup wavefront to the decoding one
+  uint32_t lk_wbase, lk_req, lk_quit;  // written by the decoding wavefront: bit position and number of the pass wanted
+  uint32_t lk_ready;              // written by the lookup wavefront: number of the pass that is in ent_buf
   uint32_t q_tail, q_eos;         // written by the decoding wavefront: entries published; 1 = no more will come
   uint32_t q_head, q_stop;        // written by the copying wavefront: entries consumed; 1 = stop decoding
   int32_t errs[2];
@@ -627,7 +632,31 @@ __device__ __forceinline__ uint32_t resolve(Smem3* sm, uint32_t sym, uint32_t ns
   return tot;
 }
 
-// ---- the two wavefronts of an image.  Wave 0 DECODES: block headers and code tables, the lane-parallel lookup, the
+// The symbols that would start at each of the 256 bit positions from wbase on (lane = position inside a window).
+__device__ __forceinline__ void span_windows(Words& in, uint32_t wbase, int lane, const Smem3* sm, uint32_t* ent) {
+  const uint32_t k = in.cover(wbase >> 5);
+  uint32_t u[2 * kSpan + 3];
+  if (k + 2 * kSpan + 3 <= 64) {
+#pragma unroll
+    for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = (uint32_t)__builtin_amdgcn_readlane((int)in.v0, (int)(k + i));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = in.word(k + i);
+  }
+  const uint32_t o = (wbase & 31) + (uint32_t)lane, j = o >> 5, sh = o & 31;  // j in {0, 1, 2}
+  uint32_t lo[kSpan], hi[kSpan];
+#pragma unroll
+  for (int r = 0; r < kSpan; ++r) {
+    const uint32_t wa = j == 0 ? u[2 * r] : (j == 1 ? u[2 * r + 1] : u[2 * r + 2]);
+    const uint32_t wb = j == 0 ? u[2 * r + 1] : (j == 1 ? u[2 * r + 2] : u[2 * r + 3]);
+    const uint32_t wc = j == 0 ? u[2 * r + 2] : (j == 1 ? u[2 * r + 3] : u[2 * r + 4]);
+    lo[r] = __builtin_amdgcn_alignbit(wb, wa, sh);
+    hi[r] = __builtin_amdgcn_alignbit(wc, wb, sh);
+  }
+  lookup_span(sm, lo, hi, ent);
+}
+
+// ---- the wavefronts of an image.  Wave 0 DECODES: block headers and code tables, the lane-parallel lookup, the
 // walk, the queue appends.  Wave 1 COPIES: batches of 64 queued symbols into the ring, finished units to HBM.  They meet
 // in the symbol queue only (LDS): the decoder publishes q_tail behind its entries, the copier q_head behind its
 // reads - LDS operations of one wavefront complete in order, so a counter read after it was written shows the data
@@ -647,6 +676,7 @@ __device__ __forceinline__ void lds_store(__attribute__((address_space(3))) uint
 }
 constexpr uint32_t kPollLimit = 1u << 22;  // polls of ~64 cycles: a wave that waits longer than this gives up (corrupt)
 
+template <bool LW>  // LW: a third wavefront does the lookups (lookup_wave); else this one does its own
 __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const uint8_t* stream, uint32_t stream_bytes,
                                            int lane, uint64_t* diag) {
   const uint32_t total_bits = stream_bytes * 8u;
@@ -680,6 +710,21 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
       __builtin_amdgcn_s_sleep(2);
     }
     return room;
+  };
+  uint32_t lk_seq = 0;  // passes requested so far
+  auto request_lookup = [&](uint32_t at) {
+    lds_store(&sm->lk_wbase, at, lane);
+    lds_store(&sm->lk_req, ++lk_seq, lane);
+  };
+  auto wait_lookup = [&]() -> bool {  // until the last requested pass is in ent_buf
+    for (uint32_t polls = 0; lds_load(&sm->lk_ready) != lk_seq; ++polls) {
+      if (polls > kPollLimit) {
+        err = 1;
+        return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
   };
   bool last = false;
   while (!err && !stop && !last) {
@@ -728,34 +773,27 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
     // starts in a 64-bit mask per window.  Marked entries are appended to the symbol queue by their lanes.
     uint32_t wbase = bp, pos = 0;  // pass origin; next symbol's start relative to it
     bool eob = false;
+    if constexpr (LW) {
+      if (!wait_lookup()) break;   // a request of the previous block may still be in the works (its tables are gone)
+      request_lookup(wbase);
+    }
     while (!eob && !err && !stop) {
       if (wbase + pos > total_bits) {  // ran past the end of the stream
         err = 1;
         break;
       }
-      uint32_t ent[kSpan], lo[kSpan], hi[kSpan];
+      // the pass's symbols come from the lookup wavefront, which was asked for them one pass ago; the request for the
+      // NEXT pass (a fixed 256 bits on: independent of where this pass's walk ends) goes out before the walk starts
+      uint32_t ent[kSpan];
       STAMP(0);
       COUNT(2, 1);
-      {
-        const uint32_t k = in.cover(wbase >> 5);
-        uint32_t u[2 * kSpan + 3];
-        if (k + 2 * kSpan + 3 <= 64) {
+      if constexpr (LW) {
+        if (!wait_lookup()) break;
 #pragma unroll
-          for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = (uint32_t)__builtin_amdgcn_readlane((int)in.v0, (int)(k + i));
-        } else {
-#pragma unroll
-          for (int i = 0; i < 2 * kSpan + 3; ++i) u[i] = in.word(k + i);
-        }
-        const uint32_t o = (wbase & 31) + (uint32_t)lane, j = o >> 5, sh = o & 31;  // j in {0, 1, 2}
-#pragma unroll
-        for (int r = 0; r < kSpan; ++r) {
-          const uint32_t wa = j == 0 ? u[2 * r] : (j == 1 ? u[2 * r + 1] : u[2 * r + 2]);
-          const uint32_t wb = j == 0 ? u[2 * r + 1] : (j == 1 ? u[2 * r + 2] : u[2 * r + 3]);
-          const uint32_t wc = j == 0 ? u[2 * r + 2] : (j == 1 ? u[2 * r + 3] : u[2 * r + 4]);
-          lo[r] = __builtin_amdgcn_alignbit(wb, wa, sh);
-          hi[r] = __builtin_amdgcn_alignbit(wc, wb, sh);
-        }
-        lookup_span(sm, lo, hi, ent);
+        for (int r = 0; r < kSpan; ++r) ent[r] = sm->ent_buf[r][lane];
+        request_lookup(wbase + 64 * kSpan);
+      } else {
+        span_windows(in, wbase, lane, sm, ent);
       }
       STAMP(2);
       // ---- walk segments of the pass: one, plus one behind every serially decoded symbol
@@ -771,7 +809,7 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
                  n3 = (uint32_t)__popcll(m3);
         // one slot beyond the marks for a serially decoded symbol; at least a window's worth always (n0 <= 64)
         uint32_t want = n0 + n1 + n2 + n3 + 1;
-        want = want < 65 ? 65 : (want > kQueue - 1 ? kQueue - 1 : want);
+        want = want < 65 ? 65 : (want > kQueue - kBatchMin ? kQueue - kBatchMin : want);  // what the copier surely frees
         const uint32_t room = room_for(want) - 1;
         if (stop) break;
         if (n0 + n1 + n2 + n3 > room) {
@@ -803,11 +841,8 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
         if (stopped && ((e >> 7) & 3) == S_SLOW) {  // a long code: decode this one symbol serially, queue it
           STAMP(6);
           COUNT(3, 1);
-          const uint32_t r = pos >> 6;
-          const uint32_t l = r == 0 ? lo[0] : (r == 1 ? lo[1] : (r == 2 ? lo[2] : lo[3]));
-          const uint32_t h = r == 0 ? hi[0] : (r == 1 ? hi[1] : (r == 2 ? hi[2] : hi[3]));
-          e = U(lookup_slow((uint32_t)__builtin_amdgcn_readlane((int)l, (int)(pos & 63)),
-                            (uint32_t)__builtin_amdgcn_readlane((int)h, (int)(pos & 63)), sm, lane));
+          const uint64_t w64 = in.peek(wbase + pos);
+          e = U(lookup_slow((uint32_t)w64, (uint32_t)(w64 >> 32), sm, lane));
           if (e == ~0u) {
             err = 1;
             break;
@@ -835,6 +870,7 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
   }
   lds_store(&sm->q_tail, tail, lane);
   lds_store(&sm->q_eos, 1u, lane);
+  lds_store(&sm->lk_quit, 1u, lane);
 #ifdef HCIR_PNG_STAMPS
   STAMP(0);
   if (lane == 0 && diag) {
@@ -847,6 +883,35 @@ __device__ __forceinline__ int decode_wave(const PngBatch& a, Smem3* sm, const u
   return err;
 }
 
+// Wave 2 LOOKS UP: for the pass the decoder asks for (a bit position), the symbol that would start at each of its 256
+// bit positions, from the block's tables in LDS, into ent_buf.  It never looks at what the decoder does with them; a
+// request made with tables that are being replaced meanwhile gives entries nobody reads.
+__device__ __forceinline__ void lookup_wave(Smem3* sm, const uint8_t* stream, uint32_t stream_bytes, int lane) {
+  Words in;
+  in.w = reinterpret_cast<const uint32_t*>(stream);
+  in.nwords = (stream_bytes + 3) / 4 + 4;
+  in.lane = lane;
+  in.seek(0);
+  uint32_t seen = 0;
+  for (uint32_t polls = 0;;) {
+    const uint32_t quit = lds_load(&sm->lk_quit);  // read BEFORE the request counter: a request seen after "quit" is stale
+    const uint32_t req = lds_load(&sm->lk_req);
+    if (req == seen) {
+      if (quit || ++polls > kPollLimit) break;
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    polls = 0;
+    const uint32_t wbase = lds_load(&sm->lk_wbase);  // stored before the counter
+    uint32_t ent[kSpan];
+    span_windows(in, wbase, lane, sm, ent);
+#pragma unroll
+    for (int r = 0; r < kSpan; ++r) sm->ent_buf[r][lane] = ent[r];
+    seen = req;
+    lds_store(&sm->lk_ready, req, lane);
+  }
+}
+
 __device__ __forceinline__ int copy_wave(const PngBatch& a, Smem3* sm, uint8_t* raw, uint32_t need, int lane,
                                          uint64_t* diag) {
   int err = 0;
@@ -856,7 +921,7 @@ __device__ __forceinline__ int copy_wave(const PngBatch& a, Smem3* sm, uint8_t* 
     const uint32_t eos = lds_load(&sm->q_eos);  // read BEFORE the tail: a tail read after "no more" is the final one
     const uint32_t tail = lds_load(&sm->q_tail);
     const uint32_t avail = tail - head;
-    if (avail < 64 && !(eos && avail)) {
+    if (avail < kBatchMin && !(eos && avail)) {
       if (eos) break;  // drained
       if (++polls > kPollLimit) {
         err = 1;
@@ -900,7 +965,8 @@ __device__ __forceinline__ int copy_wave(const PngBatch& a, Smem3* sm, uint8_t* 
   return err;
 }
 
-__global__ __launch_bounds__(128) void png_inflate_kernel(PngBatch a) {
+template <bool LW>
+__global__ __launch_bounds__(LW ? 192 : 128) void png_inflate_kernel(PngBatch a) {
   __shared__ __attribute__((aligned(16))) Smem smem;
   Smem3* sm = (Smem3*)&smem;
 
@@ -921,6 +987,7 @@ __global__ __launch_bounds__(128) void png_inflate_kernel(PngBatch a) {
   }
   if (threadIdx.x == 0) {
     sm->q_tail = sm->q_head = sm->q_eos = sm->q_stop = 0;
+    sm->lk_req = sm->lk_ready = sm->lk_quit = sm->lk_wbase = 0;
     sm->errs[0] = sm->errs[1] = 0;
   }
   __syncthreads();
@@ -928,12 +995,14 @@ __global__ __launch_bounds__(128) void png_inflate_kernel(PngBatch a) {
 #ifdef HCIR_PNG_STAMPS
   diag = a.diag ? a.diag + img * 16 : nullptr;
 #endif
-  int err;
+  int err = 0;
   if (wave == 0)
-    err = decode_wave(a, sm, a.blob + hp->stage_offset, hp->stream_bytes, lane, diag);
-  else
+    err = decode_wave<LW>(a, sm, a.blob + hp->stage_offset, hp->stream_bytes, lane, diag);
+  else if (wave == 1)
     err = copy_wave(a, sm, a.raw + (uint64_t)img * a.raw_stride, need, lane, diag);
-  if (lane == 0) sm->errs[wave] = err;
+  else
+    lookup_wave(sm, a.blob + hp->stage_offset, hp->stream_bytes, lane);
+  if (lane == 0 && wave < 2) sm->errs[wave] = err;
   __syncthreads();
   if (threadIdx.x == 0) a.status[img] = (sm->errs[0] | sm->errs[1]) ? HCIR_ERR_INVALID : HCIR_OK;
 }
@@ -1178,7 +1247,13 @@ extern "C" int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_he
   a.raw_stride = p.raw_stride;
   a.status = status_dev ? status_dev : reinterpret_cast<int32_t*>(ws + (size_t)b * p.raw_stride);
   a.diag = reinterpret_cast<uint64_t*>(ws + (((size_t)b * p.raw_stride + (size_t)b * 4 + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(png_inflate_kernel, dim3((unsigned)b), dim3(128), 0, st, a);
+  // Up to ~600 images every CU hosts at most two or three of them: a third wavefront per image for the lookups
+  // shortens every image's serial chain (35.7 instead of 39.3 ms per 256 files).  A full chip (four images per CU)
+  // has no issue slots to spare for it (46.6 against 44.4 ms per 880 files): two wavefronts per image then.
+  if (b <= 600)
+    hipLaunchKernelGGL(png_inflate_kernel<true>, dim3((unsigned)b), dim3(192), 0, st, a);
+  else
+    hipLaunchKernelGGL(png_inflate_kernel<false>, dim3((unsigned)b), dim3(128), 0, st, a);
   HCIR_LAUNCH_CHECK();
   const size_t lds = (size_t)64 * kRawPitch + ((size_t)p.max_x1 + 64) * 4;  // + the 64 dump words behind the row
   if (p.any[1]) hipLaunchKernelGGL(png_unfilter_kernel<1>, dim3((unsigned)b), dim3(64), lds, st, a);

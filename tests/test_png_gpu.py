@@ -107,9 +107,11 @@ def test_live_pillow_sweep(hcir_built):
         np.testing.assert_array_equal(got[i], _window(_pil(f), 224, 224), err_msg=f"file {i}")
 
 
-def test_batch_of_256_and_determinism(streams, hcir_built):
+@pytest.mark.parametrize("count", [256, 704])
+def test_big_batches_and_determinism(streams, hcir_built, count):
+    """256 files: three wavefronts per image (lookup | decoder | copier); 704 files: the full-chip form, two per image."""
     names, files, wins = streams
-    order = np.random.default_rng(2).integers(0, len(files), 256)
+    order = np.random.default_rng(2).integers(0, len(files), count)
     batch = [files[i] for i in order]
     a, _ = _decode(batch)
     b, _ = _decode(batch)

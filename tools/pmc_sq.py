@@ -9,7 +9,8 @@ import collections, csv, glob, json, os, re, sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hair-centric-image-retrieval_amd"))
 
-KERNELS = [("gemm_f16_big_kernel<0", r"gemm_f16_big_kernel<0,"), ("gemm_f16_big_kernel<10", r"gemm_f16_big_kernel<10,"),
+KERNELS = [("gemm_f16_big_kernel<0", r"gemm_f16_big_kernel<0,"), ("gemm_f16_big_kernel<1", r"gemm_f16_big_kernel<1,"),
+           ("gemm_f16_big_kernel<10", r"gemm_f16_big_kernel<10,"),
            ("gemm_f16_big_kernel<6", r"gemm_f16_big_kernel<6,"), ("gemm_f16_tn_kernel", r"gemm_f16_tn_kernel"),
            ("attn_bwd2_kernel", r"attn_bwd2_kernel"), ("attn_bwd_kernel", r"attn_bwd_kernel<"),
            ("attn_fwd_kernel", r"attn_fwd_kernel"), ("layernorm_bwd_kernel", r"layernorm_bwd_kernel"),

@@ -1,6 +1,8 @@
 #!/bin/bash
 # The round's rocprofv3 evidence, run ON the GPU box from the repo root:  bash tools/profile_round.sh <outdir>
-#   1. --kernel-trace --stats over the default bench.py command          -> <outdir>/kernel_stats.csv
+#   1. --kernel-trace --stats over the bench.py command, ONE step in flight (--no-pipeline: with two steps in flight on
+#      two streams the launches overlap and every duration stretches; the roofline's own HIP-event measurement is
+#      taken on one stream too)                                           -> <outdir>/kernel_stats.csv
 #   2. --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command   -> <outdir>/pmc_traffic.json (tools/pmc_traffic.py)
 #   3. the same two passes over the 64-query streaming scan               -> <outdir>/pmc_scan.json    (tools/pmc_scan.py)
 # Counter passes run alone with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3 section); the program follows
@@ -10,7 +12,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/${1:-gpurun_out/prof}
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$O/stats" --output-format csv -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$O/bench_stats.json" 2> "$O/stats.err"; echo "stats done"
+rocprofv3 --kernel-trace --stats -d "$O/stats" --output-format csv -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-pipeline > "$O/bench_stats.json" 2> "$O/stats.err"; echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/fetch" --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> "$O/fetch.err"; echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/write" --output-format csv -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> "$O/write.err"; echo "write done"
 rocprofv3 --pmc FETCH_SIZE -d "$O/sfetch" --output-format csv -- python3 "$R/tools/scan_point.py" c4 > /dev/null 2>&1

@@ -602,8 +602,18 @@ __device__ unsigned long long g_gemm_stamps[256 * 8];
     if ((cond) && threadIdx.x == 0 && blockIdx.x < 256)                                        \
       g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                  \
   } while (0)
+// per-wavefront stamps of the overlapped boundary (gemm_f16_ov_kernel): [0..7] start, [8..15] end, [16..23] next step
+__device__ unsigned long long g_gemm_wstamps[256 * 24];
+#define HCIR_WSTAMP(cond, i)                                                                              \
+  do {                                                                                                    \
+    if ((cond) && (threadIdx.x & 63) == 0 && blockIdx.x < 256)                                            \
+      g_gemm_wstamps[blockIdx.x * 24 + 8 * (i) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
 #else
 #define HCIR_GSTAMP(cond, i) \
+  do {                       \
+  } while (0)
+#define HCIR_WSTAMP(cond, i) \
   do {                       \
   } while (0)
 #endif
@@ -830,6 +840,338 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_big_kernel(GemmArgs g, int ti
       // the DMA source offsets of the tile being issued are RE-DERIVED here instead of living through the epilogue:
       // the dual-output variant spilled them, and its reload made the compiler put vmcnt(0) in front of every DMA
       // group of the main loop (MFMA busy 39 % against 57 % for the other variants)
+      if (issue_ti < my_tiles) set_sources(issue_ti);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// EXPERIMENT (build flag HCIR_GEMM_OVERLAP, round 4; NOT the default - measured flat to 5 % slower):
+// the 256 x 256 kernel with the epilogue of tile t run INSIDE the first k-step of tile t+1 ("overlapped boundary"),
+// for the fp16-output epilogues without a residual read (qkv, fc1: 62 % of the encoder's GEMM time).
+//
+// Idea: at K = 768 a tile is 12 k-steps of 1.65 us plus 5-6 us (qkv) to 9-10 us (fc1 + GELU) in which the matrix
+// pipes and the L2 -> LDS fill both stand still.  There is no room to park a finished tile (the accumulators are half
+// of the CU's registers, the two stages 128 of its 160 KB of LDS), so the boundary is cut into EIGHT sub-passes of 4
+// accumulator blocks (64 features x 16 rows): finish the blocks in fp32 on the accumulator side -> start the SAME
+// blocks of the next tile (their MFMAs of k-step 0 with C = 0, fragments from the stage that has landed) -> store.
+// An accumulator register is re-used by the next tile the moment its old value has been packed; the step behind the
+// boundary waits with vmcnt(16) (its stage was issued BEFORE the sixteen stores; vector-memory operations retire in
+// issue order); per-tile vectors (bias, c1, LayerNorm mean / rstd) are staged in 4 KB of LDS during the tile's last
+// k-step so that they are read with ds_read instead of queueing behind the stores.  The k order of every
+// accumulator is unchanged: results are bit-identical to gemm_f16_big_kernel / gemm_f16_mid_kernel
+// (tools/cmp_gemm_variants.py, tests/test_vit_gpu.py::test_gemm_overlapped_tile_boundary).
+//
+// What the stamps say (tools/diag_gemm_stamps.py ... ov, profiles/r4_gemm_boundary_stamps.txt; batch 880):
+//   * the boundary step takes 5.6 us (qkv) / 9.4 us (fc1) against 6.5 / 11 for "barrier + epilogue + wait + first
+//     k-step" of the plain kernel, and the launch is flat: qkv 594 vs 592 us, fc1 932 vs 918 us with an LDS
+//     transposition image (first form), 613 vs 580 / 922 vs 901 us with the register exchange below;
+//   * per wavefront: the SIMD's first wavefront runs its boundary at full speed (2.4 us qkv, 4.6 us fc1), the
+//     second one only THEN (leaves at 4.5 / 8.3 us): the two instruction streams of a SIMD serialise, so the step
+//     costs the SUM of both, ~6.7 cycles per instruction, 3.5 x the essential VALU + MFMA issue time;
+//   * it is not the stores' destination (every tile storing to the same 256 rows: unchanged), not HBM, not the
+//     instruction count alone (1000 -> 700 per wavefront moved the first wavefront, not the step);
+//   * with the finish arithmetic and the stores compiled out the tile period is 20.5 us (qkv and fc1: 1.21-1.23 PF)
+//     against 24-25 / 27-28: that, not more, is what a perfect boundary would buy (-15 % on the two shapes).
+// Tiles that are not followed by another tile of the workgroup, and the ragged last row of tiles, take the plain
+// boundary (gemm_epilogue256_lds).  Requires K >= 128.
+// ---------------------------------------------------------------------------
+struct GOv {
+  static constexpr int VEC_OFF = 2 * G256::STAGE_BYTES;   // bias[256] | c1[256] | (mean, rstd)[256]
+  [[maybe_unused]] static constexpr int LDS_BYTES = VEC_OFF + 4096;   // 132 KB
+};
+
+// Second form, written for instruction count (the first one - LDS transposition image, per-store 64-bit address
+// arithmetic - spent ~1000 instructions per wavefront on 128 x 64 outputs, this one ~650):
+//   * no LDS image: two v_permlane16_swap_b32 per pair of 16-feature blocks leave every lane with 16 contiguous
+//     bytes of one output row (lanes 0-15 <-> 16-31 and 32-47 <-> 48-63 trade halves: a lane then holds features
+//     8 (q16 >> 1) .. +7 of block nt + (q16 & 1)), stored as 16 rows x 64 B per instruction;
+//   * store addresses = wave-uniform base (SGPRs) + ONE per-lane 32-bit offset for the whole boundary;
+//   * every LDS address = one of six per-lane bases + an immediate.
+__device__ __forceinline__ f16x2 cvt_pk_rne(float a, float b) {
+  return __builtin_convertvector((f32x2){a, b}, f16x2);
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_ov_boundary(const GemmArgs& g, WaveAcc<true>& acc, const char* st,
+                                                 const char* vec, int64_t m0w, int nbase, int wave_n, int wave_m,
+                                                 int lane) {
+  constexpr bool kLn = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  constexpr bool kGelu = (EPI == HCIR_EPI_BIAS_GELU_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+  asm volatile("" : "+v"(lane));   // opaque: none of the addresses below may be hoisted into the main loop
+  const int r16 = lane & 15, q16 = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // per-lane bases; everything else is an immediate (row blocks are 16 rows = 2048 B apart, and a block's swizzle
+  // only depends on r16: sim_slot_off(row + 16 j, c) = sim_slot_off(row, c) + 2048 j)
+  const char* af0 = st + sim_slot_off(wave_n * 128 + r16, q16);
+  const char* af1 = st + sim_slot_off(wave_n * 128 + r16, 4 + q16);
+  const char* bf0 = st + sim_slot_off(256 + wave_m * 64 + r16, q16);
+  const char* bf1 = st + sim_slot_off(256 + wave_m * 64 + r16, 4 + q16);
+  const char* vb = vec + (wave_n * 128 + 4 * q16) * 4;
+  const char* lnb = vec + 2048 + (wave_m * 64 + r16) * 8;
+  const uint32_t voff = (uint32_t)(((int64_t)r16 * g.ldo + 16 * (q16 & 1) + 8 * (q16 >> 1)) * 2);
+#ifndef HCIR_OV_ABL
+#define HCIR_OV_ABL 0   // timing ablations (WRONG results): 3 = every tile stores to the first 256 rows, 4 = plain (not nt) stores
+#endif
+  char* const obase = reinterpret_cast<char*>(static_cast<_Float16*>(g.out) + (HCIR_OV_ABL == 3 ? (m0w & 255) : m0w) * g.ldo + nbase);
+#pragma unroll
+  for (int hn = 0; hn < 2; ++hn) {
+    // W fragments of the next tile's k-step 0 for these four n-blocks (both 32-k halves) and the blocks' bias / c1,
+    // kept over the four row blocks
+    u32x4 afH[2][4];
+    f32x4 bH[4], cH[kLn ? 4 : 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      afH[0][q] = *reinterpret_cast<const u32x4*>(af0 + 2048 * (4 * hn + q));
+      afH[1][q] = *reinterpret_cast<const u32x4*>(af1 + 2048 * (4 * hn + q));
+      bH[q] = *reinterpret_cast<const f32x4*>(vb + 64 * (4 * hn + q));
+      if constexpr (kLn) cH[q] = *reinterpret_cast<const f32x4*>(vb + 1024 + 64 * (4 * hn + q));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const u32x4 b0 = *reinterpret_cast<const u32x4*>(bf0 + 2048 * mt);
+      const u32x4 b1 = *reinterpret_cast<const u32x4*>(bf1 + 2048 * mt);
+      f32x2 ln = {0.f, 1.f};
+      if constexpr (kLn) ln = *reinterpret_cast<const f32x2*>(lnb + 128 * mt);
+      // ---- finish the four blocks (same arithmetic, same order as gemm_epilogue256_lds_impl)
+      u32x2 o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nt = 4 * hn + q;
+        float xs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc.a[nt][mt][e];
+          if constexpr (kLn)
+            x = __builtin_fmaf(ln[1], __builtin_fmaf(-ln[0], cH[q][e], x), bH[q][e]);
+          else
+            x += bH[q][e];
+          xs[e] = x;
+        }
+        if constexpr (kGelu) {
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const gelu_f32x2 y = gelu_erf2((gelu_f32x2){xs[e], xs[e + 1]});
+            xs[e] = y[0];
+            xs[e + 1] = y[1];
+          }
+        }
+        o[q][0] = __builtin_bit_cast(uint32_t, cvt_pk_rne(xs[0], xs[1]));
+        o[q][1] = __builtin_bit_cast(uint32_t, cvt_pk_rne(xs[2], xs[3]));
+      }
+      // ---- the same blocks of the next tile: k-step 0
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc.a[4 * hn + q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            __builtin_bit_cast(f16x8, afH[0][q]), __builtin_bit_cast(f16x8, b0), zero4, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc.a[4 * hn + q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            __builtin_bit_cast(f16x8, afH[1][q]), __builtin_bit_cast(f16x8, b1), acc.a[4 * hn + q][mt], 0, 0, 0);
+      // ---- 16 rows x 64 B per store: blocks (nt, nt + 1) side by side
+      char* const orow = obase + ((int64_t)(16 * mt) * g.ldo + 64 * hn) * 2;   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(o[2 * j][0], o[2 * j + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(o[2 * j][1], o[2 * j + 1][1], false, false);
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+#if HCIR_OV_ABL == 4
+        *reinterpret_cast<u32x4*>(orow + 64 * j + voff) = v;
+#else
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(orow + 64 * j + voff));
+#endif
+      }
+      // keep hipcc from hoisting the next sub-passes' reads up here (registers); the hardware overlaps the next
+      // sub-pass's arithmetic with these MFMAs anyway (in-order issue, asynchronous matrix pipe)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_f16_ov_kernel(GemmArgs g, int tiles_n, int tiles_m) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool kLn = (EPI == EPI_LN_BIAS_F16 || EPI == EPI_LN_BIAS_GELU_F16);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: everything derived from it stays in SGPRs
+  const int wave_n = wave >> 2, wave_m = wave & 3;
+  const int ntiles = tiles_n * tiles_m;
+  const int nkc = g.k / 64;
+  const int my_tiles =
+      (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int nsteps = my_tiles * nkc;
+
+  auto tile_origin = [&](int ti, int& n0, int64_t& m0) {
+    const int t = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
+#if HCIR_GEMM_NGROUP > 0
+    const int ngrp = (HCIR_GEMM_NGROUP_WIDE > 0 && tiles_n % HCIR_GEMM_NGROUP_WIDE == 0 && tiles_n > HCIR_GEMM_NGROUP_WIDE)
+                         ? HCIR_GEMM_NGROUP_WIDE : HCIR_GEMM_NGROUP;
+    if (tiles_n % ngrp == 0 && tiles_n > ngrp) {
+      const int per = ngrp * tiles_m;
+      const int grp = t / per, rem = t - grp * per;
+      n0 = (grp * ngrp + rem % ngrp) * 256;
+      m0 = (int64_t)(rem / ngrp) * 256;
+      return;
+    }
+#endif
+    n0 = (t % tiles_n) * 256;
+    m0 = (int64_t)(t / tiles_n) * 256;
+  };
+
+  uint32_t soff[G256::NLOAD];
+  const char* wbase = nullptr;
+  const char* abase = nullptr;
+  auto set_sources = [&](int t_i) {
+    int n0;
+    int64_t m0;
+    tile_origin(t_i, n0, m0);
+    wbase = reinterpret_cast<const char*>(g.w + (int64_t)n0 * g.ldw);
+    abase = reinterpret_cast<const char*>(g.a + m0 * g.lda);
+    int otid = tid;
+    asm volatile("" : "+v"(otid));
+#pragma unroll
+    for (int i = 0; i < G256::NLOAD; ++i) {
+      const int piece = otid + G256::NT * i;
+      const int row = piece >> 3, chunk = (piece & 7) ^ ((row >> 1) & 7);
+      if (row < 256) {
+        const int nr = n0 + row > g.n - 1 ? g.n - 1 - n0 : row;
+        soff[i] = (uint32_t)(((int64_t)nr * g.ldw + chunk * 8) * 2);
+      } else {
+        int64_t mr = row - 256;
+        mr = m0 + mr > g.m - 1 ? g.m - 1 - m0 : mr;
+        soff[i] = (uint32_t)((mr * g.lda + chunk * 8) * 2);
+      }
+    }
+  };
+  int issue_ti = 0, issue_kc = 0;  // next stage to issue
+  auto issue_piece = [&](int slot, int i) {
+    lds_dma16((i < 4 ? wbase : abase) + issue_kc * 128, soff[i],
+              lds_addr(lds) + slot * G256::STAGE_BYTES + ((tid & ~63) + G256::NT * i) * 16);
+  };
+  auto issue_advance = [&]() {
+    if (++issue_kc == nkc) {
+      issue_kc = 0;
+      ++issue_ti;
+      if (issue_ti < my_tiles) set_sources(issue_ti);
+    }
+  };
+
+  WaveAcc<true> acc;
+  acc.zero();
+
+  if (nsteps > 0) {
+    set_sources(0);
+#pragma unroll
+    for (int i = 0; i < G256::NLOAD; ++i) issue_piece(0, i);
+    issue_advance();
+  }
+
+  // tile ti ends in the overlapped boundary when the workgroup has another tile behind it and all 256 rows exist
+  int n0c = 0;
+  int64_t m0c = 0;
+  bool ov = false;
+  auto enter_tile = [&](int ti) {
+    tile_origin(ti, n0c, m0c);
+    ov = ti + 1 < my_tiles && m0c + 256 <= g.m;
+  };
+  if (my_tiles > 0) enter_tile(0);
+
+  const int r16 = lane & 15, kq = lane >> 4;
+  int kc = 0, ti = 0;
+  bool stores_behind = false;   // the step follows a boundary step: its stage is older than that step's 16 stores
+  for (int step = 0; step < nsteps; ++step) {
+    if (stores_behind)
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stores_behind = false;
+    __builtin_amdgcn_s_barrier();
+    HCIR_GSTAMP(ti == 1 && kc == 1, 0);   // diagnostic build: first ordinary k-step of the workgroup's second tile
+    HCIR_GSTAMP(ti == 2 && kc == 1, 5);
+    HCIR_WSTAMP(ti == 2 && kc == 1, 2);
+#ifdef HCIR_DIAG_GSTAMPS
+    if (kc == 1 && (ti == 1 || ti == 2) && threadIdx.x == 0 && blockIdx.x < 256)
+      g_gemm_stamps[blockIdx.x * 8 + (ti == 1 ? 6 : 7)] = __builtin_amdgcn_s_memtime();
+#endif
+
+    const char* st = lds + (step & 1) * G256::STAGE_BYTES;
+    const bool do_issue = step + 1 < nsteps;
+    const int islot = (step + 1) & 1;
+    // last k-step of a tile that ends in the overlapped boundary: request its per-tile vectors (older than this step's
+    // transfers, so they are back before the boundary's wait); they go to LDS at the top of the boundary step
+    const bool fetch_vec = ov && kc == nkc - 1;
+    float v0 = 0.f, v1 = 0.f;
+    if (fetch_vec) {
+      if (tid < 256) {
+        if (g.bias) v0 = g.bias[n0c + tid];
+      } else if constexpr (kLn) {
+        v0 = g.ln_c1[n0c + tid - 256];
+      }
+      if constexpr (kLn) v1 = g.ln_stats[2 * m0c + tid];   // 256 full rows: in range
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      const int chunk = 4 * ks2 + kq;
+      u32x4 bf[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        bf[mt] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(256 + wave_m * 64 + mt * 16 + r16, chunk));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        u32x4 af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          af[q] = *reinterpret_cast<const u32x4*>(st + sim_slot_off(wave_n * 128 + (4 * half + q) * 16 + r16, chunk));
+        if (do_issue && ks2 == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issue_piece(islot, 4 * half + i);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc.a[4 * half + q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(f16x8, af[q]), __builtin_bit_cast(f16x8, bf[mt]), acc.a[4 * half + q][mt], 0, 0, 0);
+      }
+    }
+    if (do_issue) issue_advance();
+
+    if (++kc == nkc) {
+      if (ov) {
+        // ---- boundary step = epilogue of tile ti + k-step 0 of tile ti+1 (step + 1)
+        ++step;
+        HCIR_GSTAMP(ti == 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* vec = lds + GOv::VEC_OFF;
+        reinterpret_cast<float*>(vec)[tid] = v0;
+        if constexpr (kLn) reinterpret_cast<float*>(vec)[512 + tid] = v1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        HCIR_GSTAMP(ti == 1, 2);
+        const char* st1 = lds + (step & 1) * G256::STAGE_BYTES;
+        if (step + 1 < nsteps) {   // always: nkc >= 2
+#pragma unroll
+          for (int i = 0; i < G256::NLOAD; ++i) issue_piece((step + 1) & 1, i);
+          issue_advance();
+        }
+        HCIR_GSTAMP(ti == 1, 3);
+        HCIR_WSTAMP(ti == 1, 0);
+        gemm_ov_boundary<EPI>(g, acc, st1, vec,
+                              m0c + wave_m * 64, n0c + wave_n * 128, wave_n, wave_m, lane);
+        HCIR_GSTAMP(ti == 1, 4);
+        HCIR_WSTAMP(ti == 1, 1);
+        stores_behind = true;
+        kc = 1;
+      } else {
+        __builtin_amdgcn_s_barrier();
+        gemm_epilogue256_lds<EPI, true>(g, acc, lds + (step & 1) * G256::STAGE_BYTES + wave * 8192,
+                                        m0c + wave_m * 64, n0c + wave_n * 128, lane);
+        acc.zero();
+        kc = 0;
+      }
+      ++ti;
+      if (ti < my_tiles) enter_tile(ti);
       if (issue_ti < my_tiles) set_sources(issue_ti);
     }
   }
@@ -1423,6 +1765,33 @@ inline bool gemm_takes_big(int64_t m, int n, int k) { return k % 64 == 0 && m >=
 template <int EPI>
 void launch_gemm_mid(const GemmArgs& g, hipStream_t st);
 
+// The 256 x 256 persistent kernel over tn x tm tiles (with -DHCIR_GEMM_OVERLAP: the overlapped-boundary experiment
+// for the epilogues it covers, when some workgroup gets a second tile).
+template <int EPI>
+void launch_big_tiles(const GemmArgs& g, int tn, int tm, hipStream_t st) {
+  const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
+#ifdef HCIR_GEMM_MFMA32
+  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+#else
+#ifdef HCIR_GEMM_OVERLAP   // EXPERIMENT (build flag; measured flat to -5 %, see the kernel's header): off by default
+  if constexpr (EPI == HCIR_EPI_BIAS_F16 || EPI == HCIR_EPI_BIAS_GELU_F16 || EPI == EPI_LN_BIAS_F16 ||
+                EPI == EPI_LN_BIAS_GELU_F16) {
+    if (g.k >= 128 && tn * tm > grid) {
+      // 148 KB of dynamic LDS: one attribute call per instantiation; a refusal falls back to the plain kernel
+      static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ov_kernel<EPI>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   GOv::LDS_BYTES) == hipSuccess;
+      if (attr) {
+        hipLaunchKernelGGL((gemm_f16_ov_kernel<EPI>), dim3(grid), dim3(512), GOv::LDS_BYTES, st, g, tn, tm);
+        return;
+      }
+    }
+  }
+#endif
+  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
+#endif
+}
+
 template <int EPI>
 void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
 #ifdef HCIR_GEMM_MID
@@ -1432,7 +1801,6 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
   }
 #endif
   const int tn = (int)hcir_cdiv(g.n, 256), tm = (int)hcir_cdiv(g.m, 256);
-  const int grid = tn * tm < 256 ? tn * tm : 256;  // persistent: one workgroup per CU
 #if !defined(HCIR_GEMM_NO_TAIL_SPLIT) && !defined(HCIR_GEMM_MFMA32)
   // Tail split: when the last round of 256 x 256 tiles would be less than half full (64 images: fc1 = 600 tiles = 2.34
   // rounds; ViT-L/14 at 128 images: 516 / 1548 / 2064 tiles = 2.02 / 6.05 / 8.06 rounds - a whole round for a sliver),
@@ -1457,8 +1825,7 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
       if (g.resid) g2.resid = static_cast<const char*>(g.resid) + obytes;
       if (g.ln_stats) g2.ln_stats = g.ln_stats + 2 * m1;
       if (g.stats_part) g2.stats_part = g.stats_part + 2 * m1;
-      hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(tm1 * tn < 256 ? tm1 * tn : 256), dim3(512), 0, st, g1, tn,
-                         tm1);
+      launch_big_tiles<EPI>(g1, tn, tm1, st);
       launch_gemm_mid<EPI>(g2, st);
       return;
     }
@@ -1477,11 +1844,7 @@ void launch_gemm_big(const GemmArgs& g, hipStream_t st) {
 #endif
   // MFMA shape: a BUILD flag (make CXXFLAGS+=-DHCIR_GEMM_MFMA32 builds the 32x32x16 variant for A/B runs through
   // HCIR_LIB_PATH); the library reads no environment variables
-#ifdef HCIR_GEMM_MFMA32
-  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, false>), dim3(grid), dim3(512), 0, st, g, tn, tm);
-#else
-  hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, true>), dim3(grid), dim3(512), 0, st, g, tn, tm);
-#endif
+  launch_big_tiles<EPI>(g, tn, tm, st);
 }
 
 // (mean, M2) of the 64-feature slices of hcir_gemm_f16_fused -> (mean, rstd) per row by Chan's parallel-variance
@@ -1578,6 +1941,9 @@ int hcir_gemm_f16_gelu_dual(const void* a, int64_t lda, const void* w, int64_t l
 #ifdef HCIR_DIAG_GSTAMPS
 int hcir_debug_gemm_stamps(unsigned long long* host_dst) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 256 * 8);
+}
+int hcir_debug_gemm_wstamps(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_gemm_wstamps), sizeof(unsigned long long) * 256 * 24);
 }
 #endif
 

@@ -176,6 +176,59 @@ def test_gemm_small_m_persistent(L, m, n, k, epi):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("m,n,k", [(197 * 300 + 5, 2304, 768), (197 * 220, 3072, 768), (70001, 512, 128)])
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_many_tiles_per_workgroup(L, m, n, k, ln, epi):
+    """Several 256 x 256 tiles per workgroup (23-32 at the benchmark's batch), ragged last row of tiles, plain and
+    LayerNorm-folded fp16 epilogues.  (1) fp32 reference; (2) a row range of the same problem small enough for the
+    128 x 192 kernel (same k order, same epilogue arithmetic) must give the SAME BITS; (3) run-to-run bit-identity.
+    Also the gate of the overlapped-boundary experiment (-DHCIR_GEMM_OVERLAP: tile t finished inside the first k-step
+    of tile t+1, gemm_f16_ov_kernel) - it has to pass this test unchanged."""
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    a = (torch.randn(m, k, device="cuda", generator=g) * 0.5 + torch.randn(m, 1, device="cuda", generator=g)).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    x = a.float()
+    stats = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-6).rsqrt()], 1).contiguous()
+    c1 = w.float().sum(1)
+
+    def run(rows0, nrows, out):
+        ap = a.data_ptr() + rows0 * k * 2
+        if ln:
+            return L.hcir_gemm_f16_fused(ap, k, w.data_ptr(), k, bias.data_ptr(), None, nrows, n, k, epi, out.data_ptr(),
+                                         n, stats.data_ptr() + rows0 * 8, c1.data_ptr(), None, _st())
+        return L.hcir_gemm_f16(ap, k, w.data_ptr(), k, bias.data_ptr(), None, nrows, n, k, epi, out.data_ptr(), n, _st())
+
+    outs = []
+    for rep in range(2):
+        out = torch.full((m, n), float("nan"), dtype=torch.float16, device="cuda")
+        assert run(0, m, out) == 0
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0]
+    assert torch.isfinite(got).all()
+    for r0 in range(0, m, 8192):                       # reference in row blocks (memory)
+        r1 = min(m, r0 + 8192)
+        xa = a[r0:r1].float()
+        if ln:
+            xa = (xa - stats[r0:r1, :1]) * stats[r0:r1, 1:]
+        want = xa @ w.float().t() + bias
+        if epi == 1:
+            want = F.gelu(want)
+        err = (got[r0:r1].float() - want).abs().max().item()
+        assert err <= 3e-3 * max(1.0, want.abs().max().item()), (r0, err)
+    # the same rows through the 128 x 192 kernel (a launch of < 0.7 rounds of 256 x 256 tiles takes it)
+    tn = n // 256
+    nrows = max(1024, (150 // tn) * 256)
+    for rows0 in (0, ((m // 2) // 256) * 256 + 256, m - nrows):
+        part = torch.full((nrows, n), float("nan"), dtype=torch.float16, device="cuda")
+        assert run(rows0, nrows, part) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(part, got[rows0:rows0 + nrows]), rows0
+
+
 @pytest.mark.parametrize("m,d,mlp", [(1500, 256, 512), (197 * 6, 768, 3072), (197 * 64, 768, 3072)])
 def test_gemm_fused_layernorm(L, m, d, mlp):
     """hcir_gemm_f16_fused: (1) the fp16-residual epilogue also emits per-row (sum, sumsq) slices ->

@@ -668,7 +668,12 @@ def main():
         cores = host_cores()
         t1 = time.perf_counter()
         staged = [hcodec.stage_batch(batch_files, threads=cores) for _ in range(2)]
-        stage_s = (time.perf_counter() - t1) / 2
+        stage_first_s = (time.perf_counter() - t1) / 2          # includes allocating (pinning) the blob
+        # steady state of a loader: its two pinned blobs are recycled (stage_batch(out=...): no allocation, one call)
+        t1 = time.perf_counter()
+        for r in range(6):
+            staged[r % 2] = hcodec.stage_batch(batch_files, threads=cores, out=staged[r % 2].blob)
+        stage_s = (time.perf_counter() - t1) / 6
         stream_bytes = staged[0].stream_bytes()
         file_bytes = sum(len(f) for f in batch_files)
         # parity of this very batch's first images against the reference decoder (PIL), then timing
@@ -708,9 +713,16 @@ def main():
                 if i >= 1:
                     j = (i - 1) % 2
                     main.wait_event(copied[j])
-                    step(xin=knn_transform_u8(wins[j]))
-                    consumed[j].record(main)
-            drain()
+                    xin = knn_transform_u8(wins[j])
+                    consumed[j].record(main)          # the window buffer is free once the transform has read it
+                    if pipe is not None:              # two steps in flight, as in the timed loop above
+                        pipe.submit(xin)
+                    else:
+                        step(xin=xin)
+            if pipe is not None:
+                pipe.drain()
+            else:
+                drain()
 
         run(2)
         torch.cuda.synchronize()
@@ -747,6 +759,7 @@ def main():
                 "compressed_stream_GBps": stream_bytes / (dec_ms * 1e-3) / 1e9,
                 "file_bytes_per_image": file_bytes / args.batch,
                 "host_stage_img_per_s": args.batch / stage_s, "host_stage_threads": cores,
+                "host_stage_first_call_img_per_s": args.batch / stage_first_s,
                 "cpu_baseline": {"value": pil_rate, "unit": "images/sec", "cores": cores, "kind": "reference",
                                  "sample": f"{len(sample)} of the same files: PIL ({lib}) full decode + "
                                            f"CenterCrop(224) on {cores} threads"}}

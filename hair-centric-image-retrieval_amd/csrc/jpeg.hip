@@ -566,9 +566,13 @@ extern "C" int hcir_jpeg_stage_batch(const uint8_t* const* files, const size_t* 
                                      size_t blob_cap, size_t* blob_used, int32_t* status, int32_t nthreads) {
   if (!files || !nbytes || !blob_used || !status || b <= 0) return HCIR_ERR_INVALID;
   const size_t hdr_bytes = jpeg_host::align16((size_t)b * sizeof(hcir_jpeg_header));
+  const bool too_small = blob && blob_cap < hdr_bytes;   // not even the headers fit: size it like the sizing call
+  const bool fill = blob != nullptr && !too_small;
   std::vector<size_t> off((size_t)b + 1, 0);
   std::vector<hcir_jpeg_header> tmp;
-  if (!blob) tmp.resize((size_t)b);
+  if (!fill) tmp.resize((size_t)b);
+  hcir_jpeg_header* hdrs = fill ? reinterpret_cast<hcir_jpeg_header*>(blob) : tmp.data();
+  std::vector<jpeg_host::Scan> scans((size_t)b);
   auto run = [&](auto&& fn) {
     const int nt = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
     std::atomic<int64_t> next{0};
@@ -580,27 +584,26 @@ extern "C" int hcir_jpeg_stage_batch(const uint8_t* const* files, const size_t* 
     work();
     for (auto& t : th) t.join();
   };
-  // pass 1: parse, per-file bound
+  // pass 1: marker walk (headers and tables only - the entropy-coded bytes are not touched), per-file bound.  With a
+  // blob the headers are parsed in place, once.
   std::vector<size_t> bound((size_t)b, 0);
   run([&](int64_t i) {
-    hcir_jpeg_header h;
-    jpeg_host::Scan sc;
-    status[i] = files[i] ? jpeg_host::parse(files[i], nbytes[i], &h, &sc) : HCIR_ERR_INVALID;
-    bound[(size_t)i] = status[i] == HCIR_OK ? jpeg_host::stage_bound(h, sc) : 0;
+    status[i] = files[i] ? jpeg_host::parse(files[i], nbytes[i], &hdrs[i], &scans[(size_t)i]) : HCIR_ERR_INVALID;
+    bound[(size_t)i] = status[i] == HCIR_OK ? jpeg_host::stage_bound(hdrs[i], scans[(size_t)i]) : 0;
   });
   off[0] = hdr_bytes;
   for (int64_t i = 0; i < b; ++i) off[(size_t)i + 1] = off[(size_t)i] + bound[(size_t)i];
   *blob_used = off[(size_t)b];
-  if (!blob) return HCIR_OK;
+  if (!fill) return too_small ? HCIR_ERR_WORKSPACE : HCIR_OK;
   if (blob_cap < off[(size_t)b]) return HCIR_ERR_WORKSPACE;
-  hcir_jpeg_header* hdrs = reinterpret_cast<hcir_jpeg_header*>(blob);
+  // pass 2: the staging copies
   run([&](int64_t i) {
-    if (status[i] != HCIR_OK) {
-      memset(&hdrs[i], 0, sizeof(hcir_jpeg_header));  // width 0: the device skips the image (its window stays zero)
-      return;
+    if (status[i] == HCIR_OK) {
+      size_t used = 0;
+      hdrs[i].stage_offset = off[(size_t)i];
+      status[i] = jpeg_host::stage(&hdrs[i], scans[(size_t)i], blob + off[(size_t)i], &used);
     }
-    size_t used = 0;
-    status[i] = hcir_jpeg_stage(files[i], nbytes[i], &hdrs[i], blob, off[(size_t)i], blob_cap, &used);
+    // width 0: the device skips the image (its window stays zero)
     if (status[i] != HCIR_OK) memset(&hdrs[i], 0, sizeof(hcir_jpeg_header));
   });
   return HCIR_OK;

@@ -92,7 +92,7 @@ inline int derive_table(int is_ac, const uint8_t bits[16], const uint8_t* vals, 
 
 struct Scan {
   const uint8_t* data;  // first entropy-coded byte
-  size_t nbytes;        // up to (excluding) the first marker that is neither RSTn nor a stuffed FF
+  size_t nbytes;        // upper bound (the rest of the file); the segment ends at the first marker that is neither RSTn nor a stuffed FF
 };
 
 // Marker walk.  Fills everything of *h except the stream fields; *scan = the entropy-coded bytes.
@@ -219,23 +219,10 @@ inline int parse(const uint8_t* f, size_t n, hcir_jpeg_header* h, Scan* scan) {
   const int64_t mcus = (int64_t)h->mcus_x * h->mcus_y;
   if (mcus * nb >= (int64_t(1) << 31)) return HCIR_ERR_UNSUPPORTED;
   h->nsegments = h->restart_interval > 0 ? (int32_t)((mcus + h->restart_interval - 1) / h->restart_interval) : 1;
-  // entropy-coded segment: ends at the first FF that is followed by neither 00, RSTn nor another FF
+  // entropy-coded segment: from here to the first FF that is followed by neither 00, RSTn nor another FF.  The
+  // parse does not look for that end (a pass over the whole file); stage() stops there, nbytes is the upper bound.
   scan->data = f + i;
-  size_t e = i;
-  while (e < n) {
-    const uint8_t* q = (const uint8_t*)memchr(f + e, 0xFF, n - e);
-    if (!q) {
-      e = n;
-      break;
-    }
-    e = (size_t)(q - f);
-    if (e + 1 >= n) break;
-    const uint8_t nb2 = f[e + 1];
-    if (nb2 == 0x00 || (nb2 >= 0xD0 && nb2 <= 0xD7)) e += 2;
-    else if (nb2 == 0xFF) e += 1;
-    else break;
-  }
-  scan->nbytes = e - i;
+  scan->nbytes = n - i;
   return HCIR_OK;
 }
 
@@ -268,8 +255,10 @@ inline int stage(hcir_jpeg_header* h, const Scan& s, uint8_t* dst, size_t* used)
       if ((int64_t)seg.size() >= h->nsegments) return HCIR_ERR_INVALID;  // more RSTn than the frame has intervals
       seg.push_back((uint32_t)(nout * 8));
       p = q + 2;
-    } else {
+    } else if (nb == 0xFF) {
       p = q + 1;  // fill byte in front of a marker
+    } else {
+      break;      // a marker: the entropy-coded segment ends here
     }
   }
   if (nout * 8 >= (uint64_t(1) << 31)) return HCIR_ERR_UNSUPPORTED;

@@ -77,8 +77,10 @@ class StagedBatch:
 
 
 def stage_batch(files: Sequence[Bytes], pin: Optional[bool] = None, threads: int = 8,
-                verify_crc: bool = True) -> StagedBatch:
-    """Parse + stage every file into one blob (hcir_png_stage_batch).  Host only; needs no GPU."""
+                verify_crc: bool = True, out: Optional[torch.Tensor] = None) -> StagedBatch:
+    """Parse + stage every file into one blob (hcir_png_stage_batch).  Host only; needs no GPU.
+    `out`: a host uint8 blob to stage into (a loader recycles its pinned blobs); a blob that is too small is replaced
+    by a fresh one."""
     L = _lib.lib()
     arrs = [_as_u8(f) for f in files]
     b = len(arrs)
@@ -89,8 +91,18 @@ def stage_batch(files: Sequence[Bytes], pin: Optional[bool] = None, threads: int
     status = np.zeros(b, dtype=np.int32)
     used = ctypes.c_size_t(0)
     flags = VERIFY_CRC if verify_crc else 0
-    check(L.hcir_png_stage_batch(ptrs, lens, b, flags, None, 0, ctypes.byref(used), status.ctypes.data, threads),
-          "hcir_png_stage_batch(size)")
+    if out is not None:
+        if out.is_cuda or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise HcirError("stage_batch(out=...) needs a contiguous host uint8 tensor")
+        rc = L.hcir_png_stage_batch(ptrs, lens, b, flags, out.data_ptr(), out.numel(), ctypes.byref(used),
+                                    status.ctypes.data, threads)
+        if rc == 0:
+            return StagedBatch(out[:used.value], b, status)
+        if rc != -4:                      # anything but HCIR_ERR_WORKSPACE
+            check(rc, "hcir_png_stage_batch")
+    else:
+        check(L.hcir_png_stage_batch(ptrs, lens, b, flags, None, 0, ctypes.byref(used), status.ctypes.data, threads),
+              "hcir_png_stage_batch(size)")
     if pin is None:
         pin = torch.cuda.is_available()
     blob = torch.empty(used.value, dtype=torch.uint8, pin_memory=bool(pin))

@@ -510,7 +510,9 @@ int hcir_jpeg_stage(const uint8_t* file, size_t nbytes, hcir_jpeg_header* hdr, u
 /* HOST.  The same for b files into one blob (headers at blob[0 .. b * sizeof(hcir_jpeg_header)), streams behind),
  * `nthreads` worker threads.  status[i] = per-file result; a rejected file gets a zeroed header (width 0), which
  * hcir_jpeg_decode_window_u8 skips (its window stays zero; the loader decodes that file on the host).
- * blob == NULL: only *blob_used (bytes to allocate) and status[] are produced. */
+ * blob == NULL: only *blob_used (bytes to allocate: an upper bound from the file sizes, the entropy-coded bytes are
+ * not read) and status[] are produced.  A blob that is too small: HCIR_ERR_WORKSPACE with *blob_used set - a loader
+ * that recycles its (pinned) blobs calls once per batch and re-allocates only then. */
 int hcir_jpeg_stage_batch(const uint8_t* const* files, const size_t* nbytes, int64_t b, uint8_t* blob,
                           size_t blob_cap, size_t* blob_used, int32_t* status, int32_t nthreads);
 /* HOST.  Workspace bytes for a batch (per-image strides are the maxima over the batch). */

@@ -151,6 +151,42 @@ def test_stage_rejects_truncated_and_garbage(hcir_built):
     assert staged.status[0] == 0 and all(s != 0 for s in staged.status[1:]), staged.status
 
 
+def test_stage_batch_recycled_blob_and_scan_end(streams, hcir_built):
+    """A loader recycles its blobs: stage_batch(out=...) stages in place, byte-identical to a fresh blob; a blob that
+    is too small is replaced.  The entropy-coded segment ends at the first real marker - bytes behind EOI (a second
+    image, padding that looks like stuffing) must not reach the stream."""
+    import torch
+    from hcir import jpeg
+    names, files, _ = streams
+    fresh = jpeg.stage_batch(files, pin=False, threads=4)
+    big = torch.full((fresh.blob.numel() + 8192,), 0xA5, dtype=torch.uint8)
+    again = jpeg.stage_batch(files, pin=False, threads=3, out=big)
+    assert again.blob.data_ptr() == big.data_ptr()
+    np.testing.assert_array_equal(again.status, fresh.status)
+    # identical wherever something is defined (the gaps between a file's bound and what it used are not written)
+    hf, ha = fresh.headers(), again.headers()
+    bf, ba = fresh.blob.numpy(), again.blob.numpy()
+    for i in range(len(files)):
+        assert bytes(hf[i]) == bytes(ha[i])
+        if fresh.status[i] == 0:
+            n = 4 * hf[i].stream_words                      # the words, then (16-byte aligned) the segment table
+            t, tn = (n + 15) // 16 * 16, 4 * (hf[i].nsegments + 1)
+            oa, of = ha[i].stage_offset, hf[i].stage_offset
+            np.testing.assert_array_equal(ba[oa:oa + n], bf[of:of + n])
+            np.testing.assert_array_equal(ba[oa + t:oa + t + tn], bf[of + t:of + t + tn])
+    small = torch.zeros(1000, dtype=torch.uint8)
+    repl = jpeg.stage_batch(files, pin=False, out=small)
+    assert repl.blob.data_ptr() != small.data_ptr() and repl.blob.numel() == fresh.blob.numel()
+    rng = np.random.default_rng(5)
+    good = _encode(_synth(rng, 96, 80), quality=85)
+    tail = good + b"\xff\x00\xff\xd0" + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) + good
+    a, b2 = jpeg.stage_batch([good], pin=False), jpeg.stage_batch([tail], pin=False)
+    ha, hb = a.headers()[0], b2.headers()[0]
+    assert hb.stream_bits == ha.stream_bits and hb.stream_words == ha.stream_words
+    np.testing.assert_array_equal(b2.blob.numpy()[hb.stage_offset:hb.stage_offset + 4 * hb.stream_words],
+                                  a.blob.numpy()[ha.stage_offset:ha.stage_offset + 4 * ha.stream_words])
+
+
 def test_emulated_device_path_matches_golden(streams, emul):
     names, files, wins = streams
     for name, data, win in zip(names, files, wins):

@@ -390,8 +390,15 @@ __device__ __forceinline__ void gemm_epilogue256_lds_impl(const GemmArgs& g, con
             const int64_t mm = m0w + (it0 + u) * 8 + rrow;
 #pragma unroll
             for (int e = 0; e < 8; ++e) oldh[u][e] = (_Float16)0.f;
+            // (-DHCIR_EPI_ABL_NOOLD: timing ablation, WRONG results - the residual rows are not read: proj 237 -> 201 us,
+            // fc2 709 -> 686 us at batch 880.  Requesting all sixteen pieces of the tile during its last k-step instead
+            // (registers freed by keeping the bias in LDS; bit-identical) made proj 3.5 % and fc2 1.3 % SLOWER: the
+            // 128 KB a tile reads here go through the same L2 -> CU path as its stages, and that path is what bounds
+            // the main loop - profiles/r4_gemm_resid_prefetch.txt)
+#ifndef HCIR_EPI_ABL_NOOLD
             if (FULL || mm < g.m)
               oldh[u] = *reinterpret_cast<const f16x8*>(static_cast<const _Float16*>(g.resid) + mm * g.ldo + n);
+#endif
           }
         }
 #pragma unroll

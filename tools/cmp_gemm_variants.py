@@ -63,6 +63,34 @@ def main():
                 idx = torch.nonzero(~(d == 0))
                 print("   first differing (row, col):", idx[:5].tolist(), "count", idx.shape[0],
                       "nan", torch.isnan(outs[0]).sum().item())
+    # fp16-residual epilogues (proj / fc2): in place, out of place, and with the LayerNorm statistics by-product
+    for (m, n, k) in ((197 * 100, 768, 768), (197 * 300 + 5, 768, 3072), (197 * 880, 768, 768), (70001, 512, 128)):
+        g = torch.Generator(device="cuda").manual_seed(m + n + 1)
+        a = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+        w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).half()
+        bias = torch.randn(n, device="cuda", generator=g)
+        resid = (torch.randn(m, n, device="cuda", generator=g) + 3.0).half()
+        nsl = n // 64
+        res = []
+        for L in (A, B):
+            o1 = resid.clone()                                    # in place
+            assert L.hcir_gemm_f16(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, 6, o1.data_ptr(), n, st) == 0
+            o2 = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)   # out of place
+            assert L.hcir_gemm_f16_resid(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, 6,
+                                         resid.data_ptr(), o2.data_ptr(), n, st) == 0
+            o3 = resid.clone()
+            part = torch.full((nsl, m, 2), float("nan"), device="cuda")
+            assert L.hcir_gemm_f16_fused(a.data_ptr(), k, w.data_ptr(), k, bias.data_ptr(), None, m, n, k, 6, o3.data_ptr(), n,
+                                         None, None, part.data_ptr(), st) == 0
+            res.append((o1, o2, o3, part))
+        torch.cuda.synchronize()
+        for nm, x, y in zip(("in place", "out of place", "with stats: rows", "with stats: slices"), res[0], res[1]):
+            eq = torch.equal(x, y) and not torch.isnan(x.float()).any().item()
+            bad += not eq
+            print(f"m={m} n={n} k={k} resid {nm}: {'equal' if eq else 'DIFFERENT'}", flush=True)
+        eq = torch.equal(res[0][0], res[0][1]) and torch.equal(res[0][0], res[0][2])
+        bad += not eq
+        print(f"m={m} n={n} k={k} resid forms agree with each other: {eq}", flush=True)
     print("RESULT", "all equal" if bad == 0 else f"{bad} differ")
     sys.exit(1 if bad else 0)
 

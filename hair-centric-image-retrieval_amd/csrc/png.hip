@@ -1275,10 +1275,16 @@ extern "C" int hcir_png_decode_window_u8(const void* blob_dev, const hcir_png_he
   a.raw_stride = p.raw_stride;
   a.status = status_dev ? status_dev : reinterpret_cast<int32_t*>(ws + (size_t)b * p.raw_stride);
   a.diag = reinterpret_cast<uint64_t*>(ws + (((size_t)b * p.raw_stride + (size_t)b * 4 + 255) & ~(size_t)255));
-  // Up to ~600 images every CU hosts at most two or three of them: a third wavefront per image for the lookups
-  // shortens every image's serial chain (35.7 instead of 39.3 ms per 256 files).  A full chip (four images per CU)
-  // has no issue slots to spare for it (46.6 against 44.4 ms per 880 files): two wavefronts per image then.
-  if (b <= 600)
+  // A third wavefront per image does the lookups (png_inflate_kernel<true>): it shortens every image's serial chain.
+  // Before the literal pairs a full chip (four images per CU) had no issue slots to spare for it (46.6 against 44.4 ms
+  // per 880 files) and launches of more than 600 images ran two wavefronts per image; with pairs the lookup is the
+  // largest share of a decoding wavefront's time and the third wavefront wins everywhere (same box, tools/ab_png.py:
+  // 256 files 26.0 against 34.8 ms, 880 files 32.4 against 39.3 ms, 1760 files 63.1 against 77.5 ms).
+  // -DHCIR_PNG_LW_MAX=<images>: A/B switch (0: never).
+#ifndef HCIR_PNG_LW_MAX
+#define HCIR_PNG_LW_MAX 0x7fffffff
+#endif
+  if (b <= HCIR_PNG_LW_MAX)
     hipLaunchKernelGGL(png_inflate_kernel<true>, dim3((unsigned)b), dim3(192), 0, st, a);
   else
     hipLaunchKernelGGL(png_inflate_kernel<false>, dim3((unsigned)b), dim3(128), 0, st, a);

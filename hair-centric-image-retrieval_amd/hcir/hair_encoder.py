@@ -104,6 +104,32 @@ class FeatureExtractor:
             return self.model.forward_features(x)[:, 0]  # CLS token
 
 
+def _sniff(a: np.ndarray):
+    """(codec, height, width) from the first bytes of a file, without a decoder: PNG (signature + IHDR at its fixed
+    place), JPEG (marker walk to the frame header); anything else - or anything odd - goes to the host decoder, which
+    also reports what is wrong with it.  Only the grouping depends on this; the stagers parse the files themselves."""
+    n = a.size
+    if n >= 26 and a[:8].tobytes() == b"\x89PNG\r\n\x1a\n" and a[12:16].tobytes() == b"IHDR":
+        w, h = int.from_bytes(a[16:20].tobytes(), "big"), int.from_bytes(a[20:24].tobytes(), "big")
+        return ("png", h, w)
+    if n >= 4 and a[0] == 0xFF and a[1] == 0xD8:
+        i = 2
+        while i + 9 < n and a[i] == 0xFF:
+            m = int(a[i + 1])
+            if m == 0xFF:
+                i += 1
+                continue
+            if 0xD0 <= m <= 0xD9 or m == 0x01:
+                break
+            ln = (int(a[i + 2]) << 8) | int(a[i + 3])
+            if m in (0xC0, 0xC1, 0xC2):
+                return ("jpeg", (int(a[i + 5]) << 8) | int(a[i + 6]), (int(a[i + 7]) << 8) | int(a[i + 8]))
+            if m == 0xDA or ln < 2:
+                break
+            i += 2 + ln
+    return ("host", 0, 0)
+
+
 class HairEncoder:
     def __init__(self, ckpt_path: Optional[str], model_name: str = "vit_base_patch16", device=None):
         self.ckpt_path = ckpt_path
@@ -117,6 +143,7 @@ class HairEncoder:
         self.model.to(self.device)
         self.model.eval()
         self.feature_extractor = FeatureExtractor(self.model)
+        self._stage_ring = {}   # device_windows: recycled pinned staging blobs per codec
         self._gallery_key = None
         self._gallery = None
         self._gallery_ref = None
@@ -171,20 +198,33 @@ class HairEncoder:
         raw = [jpeg._as_u8(f) for f in files]
         groups = {}
         for i, a in enumerate(raw):
-            with Image.open(io.BytesIO(a)) as im:  # header parse only
-                kind = "png" if im.format == "PNG" else ("jpeg" if im.format == "JPEG" else "host")
-                groups.setdefault((kind, im.size[1], im.size[0]), []).append(i)
+            groups.setdefault(_sniff(a), []).append(i)
         images = [None] * len(raw)
+        threads = min(16, os.cpu_count() or 8)
         for (kind, h, w), idx in groups.items():
             sub = [raw[i] for i in idx]
             whole = None
             host = list(range(len(sub)))
             if kind != "host":
                 mod = png if kind == "png" else jpeg
-                staged = mod.stage_batch(sub, threads=min(8, len(sub)))
+                # the staging blobs are recycled from batch to batch, two per codec in turn (pinned: no allocation, no
+                # page faults); a blob is staged into again only after the copy that read it last has finished
+                ring = self._stage_ring.setdefault(kind, {"blob": [None, None], "copied": [None, None], "turn": 0})
+                t = ring["turn"]
+                ring["turn"] ^= 1
+                if ring["copied"][t] is not None:
+                    ring["copied"][t].synchronize()
+                staged = mod.stage_batch(sub, threads=min(threads, len(sub)), out=ring["blob"][t])
+                if ring["blob"][t] is None or staged.blob.data_ptr() != ring["blob"][t].data_ptr():
+                    # first batch, or one that did not fit: a larger blob for the next turn of this slot
+                    ring["blob"][t] = torch.empty(staged.blob.numel() * 5 // 4 + 65536, dtype=torch.uint8,
+                                                  pin_memory=torch.cuda.is_available())
                 host = staged.rejected
                 if len(host) < len(sub):
-                    whole = mod.decode_windows(staged.to(self.device), (h, w), _skip_rejected_check=True)
+                    on_dev = staged.to(self.device)
+                    ring["copied"][t] = torch.cuda.Event()
+                    ring["copied"][t].record(torch.cuda.current_stream(self.device))
+                    whole = mod.decode_windows(on_dev, (h, w), _skip_rejected_check=True)
             for k, i in enumerate(idx):
                 if k in host:  # the reference's own decoder for this file
                     with Image.open(io.BytesIO(sub[k])) as im:

@@ -151,6 +151,39 @@ def test_stage_batch_and_workspace(streams, hcir_built):
         png.decode_windows(st)  # a host blob: the decoder is device-only, no CPU fallback
 
 
+def test_stage_batch_recycled_blob_and_file_sniffing(streams, hcir_built):
+    """A loader recycles its staging blobs (stage_batch(out=...)): same bytes as a fresh blob, a blob that is too small
+    is replaced; HairEncoder groups its files by a sniff of the first bytes (codec, height, width) without a decoder."""
+    import torch
+    from hcir import png
+    from hcir.hair_encoder import _sniff
+    names, files, _, _ = streams
+    fresh = png.stage_batch(files, pin=False, threads=4)
+    big = torch.full((fresh.blob.numel() + 4096,), 0x5A, dtype=torch.uint8)
+    again = png.stage_batch(files, pin=False, threads=2, out=big)
+    assert again.blob.data_ptr() == big.data_ptr() and again.blob.numel() == fresh.blob.numel()
+    np.testing.assert_array_equal(again.status, fresh.status)
+    for hf, ha in zip(fresh.headers(), again.headers()):
+        assert bytes(hf) == bytes(ha)
+        if hf.width:
+            np.testing.assert_array_equal(again.blob.numpy()[ha.stage_offset:ha.stage_offset + ha.stream_bytes],
+                                          fresh.blob.numpy()[hf.stage_offset:hf.stage_offset + hf.stream_bytes])
+    repl = png.stage_batch(files, pin=False, out=torch.zeros(64, dtype=torch.uint8))
+    assert repl.blob.numel() == fresh.blob.numel()
+    for data, h in zip(files, fresh.headers()):
+        kind, hh, ww = _sniff(np.frombuffer(data, np.uint8))
+        with Image.open(io.BytesIO(data)) as im:
+            assert (kind, ww, hh) == ("png", im.size[0], im.size[1])
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((33, 47, 3), np.uint8)).save(buf, "JPEG", quality=70, progressive=True)
+    assert _sniff(np.frombuffer(buf.getvalue(), np.uint8)) == ("jpeg", 33, 47)
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((8, 9, 3), np.uint8)).save(buf, "BMP")
+    assert _sniff(np.frombuffer(buf.getvalue(), np.uint8))[0] == "host"
+    assert _sniff(np.frombuffer(b"\x89PNG\r\n\x1a\n" + bytes(4), np.uint8))[0] == "host"   # cut short
+    assert _sniff(np.frombuffer(b"\xff\xd8\xff\xe0", np.uint8))[0] == "host"
+
+
 def test_stager_fuzz_under_sanitizers(streams):
     """The host stager (png_stage.h) against 20 000 mutated / truncated files under AddressSanitizer + UBSan."""
     import subprocess

@@ -52,6 +52,7 @@ def parse():
                          "traffic, 1-cos vs the fp32 oracle 4e-7; fp32: 1e-7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one step in flight (no second HIP stream) at N = 1")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight at N = 1 (HIP streams of the step pipeline)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip batch_sweep / vendor yardstick / PCIe-inclusive side measurements (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="query images in the CPU baseline sample")
@@ -521,7 +522,7 @@ def main():
     # partial tile rounds and the dependent-dispatch gaps of step i; every step is finished - certified, merged -
     # before the clock stops).  Several ranks keep ONE stream: the two all-gathers of a step are collectives, and
     # collectives issued from two streams may run in another order on another rank.
-    in_flight = 2 if (world == 1 and gdtype == torch.float32 and not args.no_pipeline) else 1
+    in_flight = max(1, args.in_flight) if (world == 1 and gdtype == torch.float32 and not args.no_pipeline) else 1
     pipe = None
     if in_flight > 1:
         from hcir.pipeline import StreamPipeline
